@@ -1,0 +1,10 @@
+"""genefuserust_amd — MI355X-native k-mer seed matcher behind the GeneFuseRust
+``Indexer`` interface (src/core/indexer.rs of the reference).
+
+Only the hot path lives here: index build + per-read seed mapping as HIP
+kernels for gfx950 (csrc/), the C ABI (include/gfmatch.h) and this host-side
+mirror of the reference interface.  See DESIGN.md.
+"""
+from .indexer import Fusion, Gene, GenePos, Indexer, SeqMatch, resolve_gene_slice, unpack_matches  # noqa: F401
+
+__version__ = "0.1.0"

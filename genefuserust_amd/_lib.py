@@ -1,0 +1,109 @@
+"""ctypes binding of libgfmatch.so (the C ABI of include/gfmatch.h).
+
+The shared object is built in-tree by ``__graft_entry__.build()`` /
+``genefuserust_amd/csrc/Makefile``.  There is no fallback of any kind: if the
+library is missing, importing the compute API raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgfmatch.so")
+
+GF_OK = 0
+GF_ERR_ARG = -1
+GF_ERR_HIP = -2
+GF_ERR_NO_DEVICE = -3
+GF_ERR_CAPACITY = -4
+GF_ERR_READ_TOO_LONG = -5
+GF_MAX_READ_LEN = 4096
+GF_COUNT_TOO_LONG = 255
+
+
+class GfSeqMatch(C.Structure):
+    _fields_ = [("seq_start", C.c_int32), ("seq_end", C.c_int32), ("position", C.c_int32),
+                ("contig", C.c_int16), ("pad", C.c_int16)]
+
+
+class GfHit(C.Structure):
+    _fields_ = [("read_id", C.c_int64), ("n", C.c_int32), ("pad", C.c_int32), ("m", GfSeqMatch * 2)]
+
+
+class GfOptions(C.Structure):
+    _fields_ = [("device", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class GfIndexInfo(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in (
+        "n_genes", "total_bp", "n_sites", "n_keys", "n_unique", "n_dupe_keys", "n_high_keys",
+        "n_dupe_sites", "n_buckets", "table_bytes")] + [("device", C.c_int32), ("pad", C.c_int32)]
+
+
+SEQMATCH_DTYPE = np.dtype([("seq_start", "<i4"), ("seq_end", "<i4"), ("position", "<i4"),
+                           ("contig", "<i2"), ("pad", "<i2")])
+HIT_DTYPE = np.dtype([("read_id", "<i8"), ("n", "<i4"), ("pad", "<i4"), ("m", SEQMATCH_DTYPE, (2,))])
+assert SEQMATCH_DTYPE.itemsize == 16 and HIT_DTYPE.itemsize == 48
+
+
+class GfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("gfmatch error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libgfmatch.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libgfmatch.so not found at %s — build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). gfmatch has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.gf_last_error.restype = C.c_char_p
+    L.gf_version.restype = C.c_char_p
+    L.gf_index_build.argtypes = [C.POINTER(C.c_char_p), C.POINTER(i64), i32, C.POINTER(GfOptions), C.POINTER(vp)]
+    L.gf_index_build.restype = C.c_int
+    L.gf_index_free.argtypes = [vp]
+    L.gf_index_free.restype = None
+    L.gf_index_info_get.argtypes = [vp, C.POINTER(GfIndexInfo)]
+    L.gf_index_info_get.restype = C.c_int
+    L.gf_index_fusion_seq.argtypes = [vp, i32, C.c_char_p, i64]
+    L.gf_index_fusion_seq.restype = i64
+    L.gf_index_lookup.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.gf_index_lookup.restype = C.c_int
+    L.gf_map_reads.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.gf_map_reads.restype = C.c_int
+    L.gf_map_read.argtypes = [vp, C.c_char_p, i64, C.POINTER(GfSeqMatch)]
+    L.gf_map_read.restype = C.c_int
+    L.gf_map_reads_hits.argtypes = [vp, vp, vp, i64, i64, vp, i64, C.POINTER(i64)]
+    L.gf_map_reads_hits.restype = C.c_int
+    L.gf_map_reads_device.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
+    L.gf_map_reads_device.restype = C.c_int
+    L.gf_compact_workspace_bytes.argtypes = [i64]
+    L.gf_compact_workspace_bytes.restype = i64
+    L.gf_compact_hits_device.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, vp]
+    L.gf_compact_hits_device.restype = C.c_int
+    L.gf_in_required_direction.argtypes = [C.POINTER(GfSeqMatch), i32, vp, i32]
+    L.gf_in_required_direction.restype = C.c_int
+    L.gf_set_profiling.argtypes = [vp, i32]
+    L.gf_set_profiling.restype = C.c_int
+    L.gf_last_map_kernel_ms.argtypes = [vp]
+    L.gf_last_map_kernel_ms.restype = C.c_float
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise GfError(rc, lib().gf_last_error().decode("utf-8", "replace"))
+    return rc

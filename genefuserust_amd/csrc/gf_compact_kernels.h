@@ -1,0 +1,110 @@
+// K4 — ordered compaction of the dense per-read result into gf_hit records.
+//
+// The reference returns a Vec<SeqMatch> per read (indexer.rs:252) and the caller
+// keeps only reads with two segments (fusion_mapper.rs:107-115); >99 % of reads
+// return nothing.  The mapping kernel writes a dense count byte per read; these
+// three small kernels turn the non-empty entries into a list in ascending read
+// order (deterministic: two-level exclusive scan, no atomics), which is what
+// crosses PCIe / xGMI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/gfmatch.h"
+
+#define GF_CTILE 4096
+#define GF_CTHREADS 256
+#define GF_CPER (GF_CTILE / GF_CTHREADS)
+
+__device__ __forceinline__ int gf_is_hit(uint8_t c) { return c >= 1 && c <= 2; }
+
+__device__ __forceinline__ int gf_block_exclusive_scan(int v, int* s_wave, int* total) {
+  // 256 threads = 4 waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) s_wave[wave] = x;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  *total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  return base + x - v;
+}
+
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_compact_count(const uint8_t* __restrict__ counts,
+                                                                  int64_t n,
+                                                                  uint32_t* __restrict__ tile_counts) {
+  __shared__ int s_wave[4];
+  const int64_t r0 = (int64_t)blockIdx.x * GF_CTILE + (int64_t)threadIdx.x * GF_CPER;
+  int c = 0;
+  for (int k = 0; k < GF_CPER; ++k)
+    if (r0 + k < n) c += gf_is_hit(counts[r0 + k]);
+  int total;
+  gf_block_exclusive_scan(c, s_wave, &total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = (uint32_t)total;
+}
+
+__global__ __launch_bounds__(1024) void gf_k_compact_scan(const uint32_t* __restrict__ tile_counts,
+                                                          int64_t ntiles,
+                                                          int64_t* __restrict__ tile_offsets,
+                                                          int64_t* __restrict__ d_total) {
+  __shared__ long long s_part[1024];
+  __shared__ long long s_run;
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < ntiles; b0 += 1024) {
+    const int64_t t = b0 + threadIdx.x;
+    long long v = t < ntiles ? (long long)tile_counts[t] : 0;
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+      long long y = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0;
+      __syncthreads();
+      s_part[threadIdx.x] += y;
+      __syncthreads();
+    }
+    if (t < ntiles) tile_offsets[t] = s_run + s_part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_run += s_part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *d_total = s_run;
+}
+
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_compact_write(
+    const uint8_t* __restrict__ counts, const gf_seqmatch* __restrict__ matches, int64_t n,
+    int64_t read_id_base, const int64_t* __restrict__ tile_offsets, gf_hit* __restrict__ hits,
+    int64_t cap) {
+  __shared__ int s_wave[4];
+  const int64_t r0 = (int64_t)blockIdx.x * GF_CTILE + (int64_t)threadIdx.x * GF_CPER;
+  int c = 0;
+  for (int k = 0; k < GF_CPER; ++k)
+    if (r0 + k < n) c += gf_is_hit(counts[r0 + k]);
+  int total;
+  int64_t pos = tile_offsets[blockIdx.x] + gf_block_exclusive_scan(c, s_wave, &total);
+  if (!c) return;
+  for (int k = 0; k < GF_CPER; ++k) {
+    const int64_t r = r0 + k;
+    if (r >= n) break;
+    const uint8_t cn = counts[r];
+    if (!gf_is_hit(cn)) continue;
+    if (pos < cap) {
+      gf_hit h;
+      h.read_id = read_id_base + r;
+      h.n = cn;
+      h.pad = 0;
+      h.m[0] = matches[2 * r];
+      if (cn == 2) {
+        h.m[1] = matches[2 * r + 1];
+      } else {
+        h.m[1].seq_start = 0; h.m[1].seq_end = 0; h.m[1].position = 0; h.m[1].contig = 0; h.m[1].pad = 0;
+      }
+      hits[pos] = h;
+    }
+    ++pos;
+  }
+}

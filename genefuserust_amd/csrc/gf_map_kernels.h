@@ -1,0 +1,370 @@
+// K2/K3 — Indexer::map_read on the device, one wavefront (64 lanes) per read.
+//
+// Restates src/core/indexer.rs:252-538 (map_read) and :616-679 (segment_mask):
+//   first pass   every second 16-base window votes for the diagonal
+//                GenePos{contig, position - i} of each stored site (:275-321)
+//   top two      by (count desc, key64 asc), key 0 skipped (:323-346)
+//   gate         2*count1 >= 40 and 2*count2 >= 20 (:353-360)
+//   second pass  every window classified TOP / SECOND / NONE against the two
+//                diagonals (+-1 in key64 space), spread over 16 bases (:362-521)
+//   mismatch gate (:523-535) and segment_mask (:616-679)
+//
+// Wave-per-read keeps every branch of the rare path (survivors of the gate)
+// wave-uniform.  Per read the wave
+//   1. loads the read's bytes with coalesced dword loads, converts them once to a
+//      2-bit stream + invalid-bit stream in LDS;
+//   2. cuts its windows out of LDS (lane = window), probes one 64-byte bucket of
+//      the HBM/Infinity-Cache resident table per window;
+//   3. compacts the votes into an LDS list with ballot + mbcnt prefix sums and
+//      counts equal diagonals by repeated ballot ("peel").
+// Votes are 32-bit site codes (gf_table.h); only diagonals with >= 10 votes are
+// decoded to (contig, position) — nothing smaller can survive the gate.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/gfmatch.h"
+#include "gf_table.h"
+
+#define GF_NONE_LIN 0xFFFFFFFFu
+
+__device__ __forceinline__ void gf_wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ int gf_lanes_below(uint64_t m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// One probe: the 64-byte bucket of `key`.  Returns the slot's val with the
+// overflow bit cleared, 0 when the key is absent.
+__device__ __forceinline__ uint32_t gf_lookup(const GfTable& T, uint32_t key) {
+  uint32_t b = gf_bucket_of(key, T.nbuckets);
+  for (uint32_t guard = 0; guard <= T.nbuckets; ++guard) {
+    const uint4* p = (const uint4*)(T.slots + (size_t)b * GF_SLOTS_PER_BUCKET);
+    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    uint32_t r = 0;
+    // slot = (key << 32) | val, little endian: .x/.z = val, .y/.w = key
+    r = (q0.y == key && (q0.x & GF_VAL_LOW)) ? q0.x : r;
+    r = (q0.w == key && (q0.z & GF_VAL_LOW)) ? q0.z : r;
+    r = (q1.y == key && (q1.x & GF_VAL_LOW)) ? q1.x : r;
+    r = (q1.w == key && (q1.z & GF_VAL_LOW)) ? q1.z : r;
+    r = (q2.y == key && (q2.x & GF_VAL_LOW)) ? q2.x : r;
+    r = (q2.w == key && (q2.z & GF_VAL_LOW)) ? q2.z : r;
+    r = (q3.y == key && (q3.x & GF_VAL_LOW)) ? q3.x : r;
+    r = (q3.w == key && (q3.z & GF_VAL_LOW)) ? q3.z : r;
+    if (r) return r & GF_VAL_LOW;
+    if (!(q0.x & GF_VAL_OVF)) return 0;
+    b = (b + 1 == T.nbuckets) ? 0 : b + 1;
+  }
+  return 0;
+}
+
+// Sites of a window as site codes shifted to the window's diagonal (lin - i).
+__device__ __forceinline__ int gf_sites(const GfTable& T, uint32_t val, uint32_t i, uint32_t v[5]) {
+  uint32_t type = val >> GF_TYPE_SHIFT;
+  if (type == GF_TYPE_UNIQUE) {
+    v[0] = (val & GF_LIN_MASK) - i;
+    return 1;
+  }
+  if (type == GF_TYPE_DUPES) {
+    int cnt = (int)((val >> GF_DUPE_COUNT_SHIFT) & 7u);
+    const uint32_t* d = T.dupes + (val & GF_DUPE_START_MASK);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = (k < cnt) ? d[k] - i : 0u;
+    return cnt;
+  }
+  return 0;  // absent or HIGH
+}
+
+// contig owning site code `lin` (wave-uniform callers): smallest c with lin < lin_hi[c]
+__device__ __forceinline__ int gf_contig_of(const GfTable& T, uint32_t lin) {
+  int lo = 0, hi = T.n_genes - 1;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (lin < T.lin_hi[mid]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+// key64 (indexer.rs:698-706) -> site code, GF_NONE_LIN when no vote can carry it
+__device__ __forceinline__ uint32_t gf_lin_of_key(const GfTable& T, int64_t key) {
+  int64_t c = key >> 32;
+  if (c < 0 || c >= (int64_t)T.n_genes) return GF_NONE_LIN;
+  int32_t d = (int32_t)(uint32_t)key;
+  int64_t len = (int64_t)T.gene_len[c];
+  if ((int64_t)d >= len || (int64_t)d < -(len + (int64_t)GF_LIN_PAD)) return GF_NONE_LIN;
+  return T.lin_base[c] + (uint32_t)d;
+}
+
+// inclusive end of the run starting at s (indexer.rs:644-661)
+__device__ __forceinline__ int gf_run_end(const uint8_t* mask, int L, int s, int target) {
+  int end = s + 1, g = 0;
+  while (g < GF_ALLOWED_GAP && end + g < L) {
+    int m = mask[end + g];
+    if (m > target) break;
+    if (m == target) {
+      end += g + 1;
+      g = 0;
+      continue;
+    }
+    g += 1;
+  }
+  return end - 1;
+}
+
+template <int LCAP>
+struct GfMapSmem {
+  static constexpr int NWIN1 = (LCAP - GF_KMER) / 2 + 1;
+  static constexpr int NVOTES = NWIN1 * 5;
+  uint32_t codes[LCAP / 16 + 4];
+  uint32_t inv[LCAP / 32 + 4];
+  union {
+    uint32_t votes[NVOTES];
+    struct {
+      uint8_t wcls[LCAP];
+      uint8_t mask[LCAP];
+    } p2;
+  } u;
+};
+
+template <int LCAP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gf_k_map_reads(GfTable T, const uint8_t* __restrict__ bases,
+                                                             const int64_t* __restrict__ offsets,
+                                                             int64_t n, uint8_t* __restrict__ counts,
+                                                             gf_seqmatch* __restrict__ matches) {
+  __shared__ GfMapSmem<LCAP> smem[WAVES];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  GfMapSmem<LCAP>& S = smem[wib];
+  uint8_t* codes_b = (uint8_t*)S.codes;
+  uint8_t* inv_b = (uint8_t*)S.inv;
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+
+  for (int64_t r = (int64_t)blockIdx.x * WAVES + wib; r < n; r += stride) {
+    const int64_t off0 = offsets[r];
+    const int64_t len64 = offsets[r + 1] - off0;
+    if (len64 > LCAP) {
+      if (lane == 0) counts[r] = GF_COUNT_TOO_LONG;
+      continue;
+    }
+    const int L = (int)len64;
+    if (L < GF_KMER) {  // no window (also covers malformed negative lengths)
+      if (lane == 0) counts[r] = 0;
+      continue;
+    }
+
+    // ---- 1. read -> 2-bit stream + invalid bits in LDS ----
+    const uintptr_t addr = (uintptr_t)(bases + off0);
+    const uint32_t sh = (uint32_t)(addr & 3u);
+    const uint32_t* pw = (const uint32_t*)(addr - sh);
+    const int ndw = (int)((sh + (uint32_t)L + 3u) >> 2);
+    gf_wave_lds_sync();  // previous read's LDS traffic is finished
+    for (int t0 = 0; t0 < ndw; t0 += 64) {
+      int t = t0 + lane;
+      uint32_t x = (t < ndw) ? pw[t] : 0u;
+      uint32_t code8, inv4;
+      gf_convert4(x, code8, inv4);
+      uint32_t nb = (uint32_t)__shfl_down((int)inv4, 1);
+      if (t < ndw) {
+        codes_b[t] = (uint8_t)code8;
+        if (!(lane & 1)) inv_b[t >> 1] = (uint8_t)(inv4 | (nb << 4));
+      }
+    }
+    gf_wave_lds_sync();
+
+    // ---- 2. first pass: stride-2 windows vote ----
+    const int nwin = ((L - GF_KMER) >> 1) + 1;
+    int nvotes = 0;
+    for (int w0 = 0; w0 < nwin; w0 += 64) {
+      const int w = w0 + lane;
+      const bool act = w < nwin;
+      const uint32_t i = act ? 2u * (uint32_t)w : 0u;
+      const uint32_t g = sh + i;
+      const uint32_t key = gf_window(S.codes[g >> 4], S.codes[(g >> 4) + 1], g);
+      const uint32_t bad = gf_flags16(S.inv[g >> 5], S.inv[(g >> 5) + 1], g);
+      uint32_t val = 0;
+      if (act && !bad) val = gf_lookup(T, key);
+      uint32_t v[5];
+      const int nv = gf_sites(T, val, i, v);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const bool has = k < nv;
+        const uint64_t m = __ballot(has);
+        if (m == 0) break;
+        if (has) S.u.votes[nvotes + gf_lanes_below(m)] = v[k];
+        nvotes += __popcll(m);
+      }
+    }
+
+    // count1 >= 20 and count2 >= 10 on two different diagonals need >= 30 votes
+    if (nvotes < (GF_MAJOR_KEYS + GF_MINOR_KEYS) / 2) {
+      if (lane == 0) counts[r] = 0;
+      continue;
+    }
+    gf_wave_lds_sync();
+
+    // ---- 3. peel: count equal diagonals, keep the best two with >= 10 votes ----
+    int64_t gp1 = 0, gp2 = 0;
+    int cnt1 = 0, cnt2 = 0;
+    {
+      const int nchunks = (nvotes + 63) >> 6;
+      int remaining = nvotes;
+      // dead[k] for k < 64 chunks: NVOTES/64 <= 160 for LCAP 4096 -> keep flags in LDS-free
+      // form: a vote is dead once overwritten with GF_NONE_LIN in the list itself.
+      for (int k = 0; k < nchunks && remaining >= GF_MINOR_KEYS / 2; ++k) {
+        const int idx = (k << 6) + lane;
+        uint32_t mine = (idx < nvotes) ? S.u.votes[idx] : GF_NONE_LIN;
+        uint64_t alive = __ballot(mine != GF_NONE_LIN);
+        while (alive != 0 && remaining >= GF_MINOR_KEYS / 2) {
+          const int leader = __builtin_ctzll(alive);
+          const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)mine, leader);
+          // votes equal to K in this chunk ...
+          const bool eq0 = mine == K;
+          int c = __popcll(__ballot(eq0));
+          if (eq0) mine = GF_NONE_LIN;
+          // ... and in the later chunks (marked dead in place)
+          for (int kk = k + 1; kk < nchunks; ++kk) {
+            const int j = (kk << 6) + lane;
+            const bool eq = (j < nvotes) && (S.u.votes[j] == K);
+            c += __popcll(__ballot(eq));
+            if (eq) S.u.votes[j] = GF_NONE_LIN;
+          }
+          remaining -= c;
+          alive = __ballot(mine != GF_NONE_LIN);
+          if (c >= GF_MINOR_KEYS / 2) {
+            const int ctg = gf_contig_of(T, K);
+            const int32_t d = (int32_t)(K - T.lin_base[ctg]);
+            const int64_t key64 = (int64_t)(((uint64_t)(uint32_t)ctg << 32) | (uint64_t)(uint32_t)d);
+            if (key64 != 0) {  // indexer.rs:337,342: key 0 never ranks
+              if (c > cnt1 || (c == cnt1 && key64 < gp1)) {
+                gp2 = gp1; cnt2 = cnt1; gp1 = key64; cnt1 = c;
+              } else if (c > cnt2 || (c == cnt2 && key64 < gp2)) {
+                gp2 = key64; cnt2 = c;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (cnt1 * 2 < GF_MAJOR_KEYS || cnt2 * 2 < GF_MINOR_KEYS) {
+      if (lane == 0) counts[r] = 0;
+      continue;
+    }
+
+    // ---- 4. second pass: classify every window (stride 1) ----
+    uint32_t t1a = gf_lin_of_key(T, gp1 - 1), t1b = gf_lin_of_key(T, gp1), t1c = gf_lin_of_key(T, gp1 + 1);
+    uint32_t t2a = gf_lin_of_key(T, gp2 - 1), t2b = gf_lin_of_key(T, gp2), t2c = gf_lin_of_key(T, gp2 + 1);
+    const uint32_t lin0 = gf_lin_of_key(T, 0);
+    gf_wave_lds_sync();  // votes are dead; wcls/mask reuse their LDS
+    const int nwin2 = L - GF_KMER + 1;
+    for (int w0 = 0; w0 < nwin2; w0 += 64) {
+      const int w = w0 + lane;
+      const bool act = w < nwin2;
+      const uint32_t i = act ? (uint32_t)w : 0u;
+      const uint32_t g = sh + i;
+      const uint32_t key = gf_window(S.codes[g >> 4], S.codes[(g >> 4) + 1], g);
+      const uint32_t bad = gf_flags16(S.inv[g >> 5], S.inv[(g >> 5) + 1], g);
+      uint32_t val = 0;
+      if (act && !bad) val = gf_lookup(T, key);
+      uint32_t v[5];
+      const int nv = gf_sites(T, val, i, v);
+      uint32_t cls = 0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        if (k < nv) {
+          const uint32_t x = v[k];
+          uint32_t f = 0;
+          if (x == t1a || x == t1b || x == t1c) f = 3;       // |gplong - gp1| <= 1
+          else if (x == t2a || x == t2b || x == t2c) f = 2;  // |gplong - gp2| <= 1
+          else if (x == lin0) f = 1;                         // gplong == 0
+          cls = f > cls ? f : cls;
+        }
+      }
+      if (act) S.u.p2.wcls[w] = (uint8_t)cls;
+    }
+    gf_wave_lds_sync();
+
+    // mask[j] = max class of the windows covering base j (make_mask, :716-732)
+    int mismatches = 0;
+    for (int j0 = 0; j0 < L; j0 += 64) {
+      const int j = j0 + lane;
+      uint32_t m = 0;
+      if (j < L) {
+        const int lo = j - (GF_KMER - 1) > 0 ? j - (GF_KMER - 1) : 0;
+        const int hi = j < L - GF_KMER ? j : L - GF_KMER;
+        for (int w = lo; w <= hi; ++w) {
+          uint32_t c = S.u.p2.wcls[w];
+          m = c > m ? c : m;
+        }
+        S.u.p2.mask[j] = (uint8_t)m;
+      }
+      mismatches += __popcll(__ballot(j < L && m <= 1));
+    }
+    if (mismatches > GF_MISMATCH_THRESHOLD) {
+      if (lane == 0) counts[r] = 0;
+      continue;
+    }
+    gf_wave_lds_sync();
+
+    // ---- 5. segment_mask: longest run per target, first start wins ties ----
+    int nout = 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int target = t == 0 ? 3 : 2;
+      uint32_t best = 0;  // (len << 16) | (0xFFFF - start)
+      for (int s = lane; s < L - 1; s += 64) {
+        if (S.u.p2.mask[s] != target) continue;
+        const int e = gf_run_end(S.u.p2.mask, L, s, target);
+        const uint32_t cand = ((uint32_t)(e - s) << 16) | (uint32_t)(0xFFFF - s);
+        best = cand > best ? cand : best;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)best, o);
+        best = other > best ? other : best;
+      }
+      const int blen = (int)(best >> 16);
+      if (blen > GF_THRESHOLD_LEN) {
+        if (lane == 0) {
+          const int s = 0xFFFF - (int)(best & 0xFFFFu);
+          const int64_t gp = t == 0 ? gp1 : gp2;
+          gf_seqmatch out;
+          out.seq_start = s;
+          out.seq_end = s + blen;
+          out.position = (int32_t)(uint32_t)(gp & 0xFFFFFFFFll);  // i64_to_gp, :709-714
+          out.contig = (int16_t)(gp >> 32);
+          out.pad = 0;
+          matches[2 * r + nout] = out;
+        }
+        nout += 1;
+      }
+    }
+    if (lane == 0) counts[r] = (uint8_t)nout;
+  }
+}
+
+// Test/diagnostic: k-mer -> stored sites, decoded to (contig, position).
+__global__ void gf_k_lookup(GfTable T, const uint32_t* __restrict__ ref_kmers, int64_t n,
+                            int32_t* __restrict__ out_count, int16_t* __restrict__ out_contig,
+                            int32_t* __restrict__ out_position) {
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t val = gf_lookup(T, gf_key_from_ref_kmer(ref_kmers[q]));
+    uint32_t type = val >> GF_TYPE_SHIFT;
+    if (type == GF_TYPE_HIGH) {
+      out_count[q] = -2;
+      continue;
+    }
+    uint32_t v[5];
+    int nv = gf_sites(T, val, 0u, v);
+    out_count[q] = nv;
+    for (int k = 0; k < nv; ++k) {
+      int c = gf_contig_of(T, v[k]);
+      out_contig[5 * q + k] = (int16_t)c;
+      out_position[5 * q + k] = (int32_t)(v[k] - T.lin_base[c]);
+    }
+  }
+}

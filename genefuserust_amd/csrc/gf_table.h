@@ -1,0 +1,134 @@
+// Device table format shared by the index-build and mapping kernels.
+//
+// Reference semantics reproduced (src/core/indexer.rs:179-250): k-mer ->
+//   unique site | 2..5 sites | HIGH (>=6, no sites) | absent.
+// The reference pairs an exact 2^32-bit bitmap with an FxHashMap; here one
+// probe of a 64-byte bucket answers both "present?" and "where?".
+//
+// Layout (all in HBM, sized to stay resident in the 256 MiB Infinity Cache for
+// druggable-sized panels):
+//   slots[nbuckets][8]  : uint64 = (key << 32) | val
+//   dupes[]             : uint32 site codes of the 2..5-fold keys
+//   val  bit 31         : (slot 0 of a bucket only) some key that hashes to this
+//                         bucket was placed in a later bucket -> keep probing
+//        bits 30..29    : 0 with low bits 0 = empty, 1 = unique, 2 = dupes, 3 = HIGH
+//        unique         : bits 28..0 = lin (site code)
+//        dupes          : bits 28..26 = count (2..5), bits 25..0 = first index in dupes[]
+//
+// key  = 16 bases at 2 bits each, base j of the window in bits [2j, 2j+1],
+//        code = (ascii >> 1) & 3  (A=0 C=1 T=2 G=3).  This equals the bit
+//        reversal of the reference's k-mer (indexer.rs:789-913: first base most
+//        significant, A=0 T=1 C=2 G=3), a bijection, so hit/miss decisions are
+//        exact; k-mer values never appear in any output.
+// lin  = lin_base[contig] + position (position < 0 on the reverse strand), a
+//        32-bit code of GenePos.  Contig c owns the interval
+//        [lin_base[c] - len_c - GF_LIN_PAD, lin_base[c] + len_c) so that
+//        lin - i (the vote "diagonal" GenePos{contig, position - i},
+//        indexer.rs:690-706) stays inside contig c's interval for every read
+//        offset i < GF_LIN_PAD and two different GenePos never share a code.
+#pragma once
+
+#include <stdint.h>
+
+#define GF_KMER 16
+#define GF_SLOTS_PER_BUCKET 8
+#define GF_LIN_PAD 4096u /* >= GF_MAX_READ_LEN */
+
+#define GF_VAL_OVF 0x80000000u
+#define GF_VAL_LOW 0x7FFFFFFFu
+#define GF_TYPE_SHIFT 29
+#define GF_TYPE_UNIQUE 1u
+#define GF_TYPE_DUPES 2u
+#define GF_TYPE_HIGH 3u
+#define GF_LIN_MASK 0x1FFFFFFFu
+#define GF_DUPE_COUNT_SHIFT 26
+#define GF_DUPE_START_MASK 0x03FFFFFFu
+#define GF_DUPE_EMPTY 0xFFFFFFFFu
+
+// thresholds: src/aux/global_settings.rs:23-26, src/core/indexer.rs:619-620
+#define GF_DUP_THRESHOLD 5
+#define GF_MAJOR_KEYS 40
+#define GF_MINOR_KEYS 20
+#define GF_MISMATCH_THRESHOLD 10
+#define GF_ALLOWED_GAP 10
+#define GF_THRESHOLD_LEN 20
+
+struct GfTable {
+  const uint64_t* slots;    // nbuckets * 8
+  const uint32_t* dupes;    // duplicate-site lists
+  const uint32_t* lin_base; // [n_genes]   lin of (contig, position 0)
+  const uint32_t* lin_hi;   // [n_genes]   exclusive upper end of contig's interval
+  const uint32_t* gene_len; // [n_genes]
+  uint32_t nbuckets;
+  int32_t n_genes;
+};
+
+#if defined(__HIPCC__)
+#define GF_HD __host__ __device__ __forceinline__
+#else
+#define GF_HD inline
+#endif
+
+// murmur3 finaliser: a bijection of 32-bit words, good avalanche.
+GF_HD uint32_t gf_mix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+GF_HD uint32_t gf_bucket_of(uint32_t key, uint32_t nbuckets) {
+  return (uint32_t)(((uint64_t)gf_mix32(key) * (uint64_t)nbuckets) >> 32);
+}
+
+// reverse the order of the 16 2-bit fields
+GF_HD uint32_t gf_field_reverse(uint32_t x) {
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+  x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+  return (x >> 16) | (x << 16);
+}
+
+// key of the reverse-complement window (complement = code ^ 2 under A0 C1 T2 G3)
+GF_HD uint32_t gf_revcomp_key(uint32_t key) { return gf_field_reverse(key) ^ 0xAAAAAAAAu; }
+
+// reference-coded k-mer (indexer.rs:789-913) -> device key
+GF_HD uint32_t gf_key_from_ref_kmer(uint32_t k) {
+  k = ((k >> 1) & 0x55555555u) | ((k & 0x55555555u) << 1);
+  k = ((k >> 2) & 0x33333333u) | ((k & 0x33333333u) << 2);
+  k = ((k >> 4) & 0x0F0F0F0Fu) | ((k & 0x0F0F0F0Fu) << 4);
+  k = ((k >> 8) & 0x00FF00FFu) | ((k & 0x00FF00FFu) << 8);
+  return (k >> 16) | (k << 16);
+}
+
+// 4 ASCII bases in one little-endian dword -> 8 bits of codes (first base in the
+// low bits) and 4 invalid flags.  Valid bases are exactly 'A','C','G','T'
+// (indexer.rs:825-841: anything else, lower case included, voids the window).
+GF_HD void gf_convert4(uint32_t x, uint32_t& code8, uint32_t& inv4) {
+  uint32_t y = (x >> 1) & 0x03030303u;
+  code8 = (y * 0x01041040u) >> 24;
+  // bit (b & 31) of 0x0010008A is set for b in {0x41,0x43,0x47,0x54} given (b & 0xE0) == 0x40
+  uint32_t inv = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t b = (x >> (8 * j)) & 0xFFu;
+    uint32_t ok = (((b & 0xE0u) == 0x40u) ? 1u : 0u) & (0x0010008Au >> (b & 31u));
+    inv |= (ok ^ 1u) << j;
+  }
+  inv4 = inv;
+}
+
+// 32-bit window starting at base g of a little-endian 2-bit stream held in dwords.
+GF_HD uint32_t gf_window(uint32_t lo, uint32_t hi, uint32_t g) {
+  uint32_t sh = (g & 15u) * 2u;
+  return sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+}
+
+// 16 flag bits starting at bit g of a little-endian bit stream held in dwords.
+GF_HD uint32_t gf_flags16(uint32_t lo, uint32_t hi, uint32_t g) {
+  uint32_t sh = g & 31u;
+  uint32_t v = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+  return v & 0xFFFFu;
+}

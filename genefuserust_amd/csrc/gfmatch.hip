@@ -1,0 +1,505 @@
+// gfmatch — host side of the C ABI (include/gfmatch.h) for gfx950.
+//
+// No CPU fallback lives here: every compute entry point launches the HIP
+// kernels of gf_index_kernels.h / gf_map_kernels.h / gf_compact_kernels.h or
+// fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gfmatch.h"
+#include "gf_compact_kernels.h"
+#include "gf_index_kernels.h"
+#include "gf_map_kernels.h"
+#include "gf_table.h"
+
+static_assert(sizeof(gf_seqmatch) == 16, "gf_seqmatch layout");
+static_assert(sizeof(gf_hit) == 48, "gf_hit layout");
+static_assert(GF_LIN_PAD >= GF_MAX_READ_LEN, "site-code padding must cover the longest read");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define GF_HIP(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      char buf_[512];                                                                      \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+               __FILE__, __LINE__);                                                        \
+      return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? GF_ERR_NO_DEVICE \
+                                                                        : GF_ERR_HIP,      \
+                  buf_);                                                                   \
+    }                                                                                      \
+  } while (0)
+
+// RAII: make the index's device current for the duration of a call.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t count) { return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); }
+  T* release() {
+    T* q = p;
+    p = nullptr;
+    return q;
+  }
+};
+
+}  // namespace
+
+struct gf_index {
+  int device = 0;
+  int n_cus = 256;
+  GfTable table{};
+  uint64_t* d_slots = nullptr;
+  uint32_t* d_dupes = nullptr;
+  uint32_t* d_lin_base = nullptr;
+  uint32_t* d_lin_hi = nullptr;
+  uint32_t* d_gene_len = nullptr;
+  std::vector<std::string> fusion_seq;  // Indexer.m_fusion_seq (indexer.rs:77)
+  gf_index_info info{};
+  // profiling
+  bool profiling = false;
+  bool have_events = false;
+  bool recorded = false;
+  hipEvent_t ev0{}, ev1{};
+  std::mutex prof_mu;
+
+  ~gf_index() {
+    if (d_slots) (void)hipFree(d_slots);
+    if (d_dupes) (void)hipFree(d_dupes);
+    if (d_lin_base) (void)hipFree(d_lin_base);
+    if (d_lin_hi) (void)hipFree(d_lin_hi);
+    if (d_gene_len) (void)hipFree(d_gene_len);
+    if (have_events) {
+      (void)hipEventDestroy(ev0);
+      (void)hipEventDestroy(ev1);
+    }
+  }
+};
+
+extern "C" {
+
+const char* gf_last_error(void) { return g_err.c_str(); }
+const char* gf_version(void) { return "gfmatch 0.1.0 (gfx950)"; }
+
+int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32_t n_genes,
+                   const gf_options* opts, gf_index** out_index) {
+  if (!out_index) return fail(GF_ERR_ARG, "out_index is null");
+  *out_index = nullptr;
+  if (n_genes < 0 || n_genes > 32767) return fail(GF_ERR_ARG, "n_genes must be in 0..32767 (contig is i16)");
+  if (n_genes > 0 && (!gene_seqs || !gene_lens)) return fail(GF_ERR_ARG, "gene arrays are null");
+
+  int dev = opts ? opts->device : -1;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(GF_ERR_NO_DEVICE, "no HIP device available (gfmatch has no CPU fallback)");
+  if (dev < 0) GF_HIP(hipGetDevice(&dev));
+  if (dev >= ndev) return fail(GF_ERR_NO_DEVICE, "device ordinal out of range");
+  DeviceGuard guard(dev);
+  if (!guard.ok) return fail(GF_ERR_NO_DEVICE, "hipSetDevice failed");
+
+  std::unique_ptr<gf_index> ix(new gf_index());
+  ix->device = dev;
+  hipDeviceProp_t prop;
+  GF_HIP(hipGetDeviceProperties(&prop, dev));
+  ix->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+  // --- host: upper-case the slices (indexer.rs:159), lay out the site-code space ---
+  std::vector<uint32_t> gene_off((size_t)n_genes + 1, 0), lin_base((size_t)std::max(n_genes, 1), 0),
+      lin_hi((size_t)std::max(n_genes, 1), 0), glen((size_t)std::max(n_genes, 1), 0);
+  uint64_t total = 0, lin_cursor = 0, site_bound = 0;
+  ix->fusion_seq.resize((size_t)n_genes);
+  for (int32_t c = 0; c < n_genes; ++c) {
+    int64_t len = gene_lens[c] < 0 ? 0 : gene_lens[c];
+    if (len > 0 && !gene_seqs[c]) return fail(GF_ERR_ARG, "gene sequence pointer is null");
+    if (len > (int64_t)GF_LIN_MASK) return fail(GF_ERR_CAPACITY, "gene longer than the site-code space");
+    gene_off[(size_t)c] = (uint32_t)total;
+    total += (uint64_t)len;
+    lin_base[(size_t)c] = (uint32_t)(lin_cursor + (uint64_t)len + GF_LIN_PAD);
+    lin_cursor += 2ull * (uint64_t)len + GF_LIN_PAD;
+    lin_hi[(size_t)c] = (uint32_t)lin_cursor;
+    glen[(size_t)c] = (uint32_t)len;
+    if (len > GF_KMER) site_bound += 2ull * (uint64_t)(len - GF_KMER);
+    if (lin_cursor > (uint64_t)GF_LIN_MASK || total > 0xFFFFFFFFull - 2 * GF_TILE_BASES)
+      return fail(GF_ERR_CAPACITY, "gene set too large: total span exceeds the 29-bit site-code space");
+    std::string& s = ix->fusion_seq[(size_t)c];
+    s.assign(len > 0 ? gene_seqs[c] : "", (size_t)len);
+    for (auto& ch : s)
+      if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 'a' + 'A');
+  }
+  gene_off[(size_t)n_genes] = (uint32_t)total;
+
+  const uint32_t ntiles = (uint32_t)((total + GF_TILE_BASES - 1) / GF_TILE_BASES);
+  const size_t cat_bytes = (size_t)ntiles * GF_TILE_BASES + 64;
+  std::vector<uint8_t> cat(cat_bytes, 0);
+  for (int32_t c = 0; c < n_genes; ++c)
+    memcpy(cat.data() + gene_off[(size_t)c], ix->fusion_seq[(size_t)c].data(), ix->fusion_seq[(size_t)c].size());
+
+  // 8 slots per bucket, about 4 keys per bucket on average
+  uint64_t nb64 = std::max<uint64_t>(16, (site_bound + 3) / 4);
+  if (nb64 > 0x7FFFFFFFull) return fail(GF_ERR_CAPACITY, "table too large");
+  const uint32_t nbuckets = (uint32_t)nb64;
+  const uint64_t nslots = (uint64_t)nbuckets * GF_SLOTS_PER_BUCKET;
+
+  DevBuf<uint8_t> d_cat;
+  DevBuf<uint32_t> d_goff;
+  DevBuf<unsigned long long> d_stats;
+  GF_HIP(d_cat.alloc(cat_bytes));
+  GF_HIP(d_goff.alloc((size_t)n_genes + 1));
+  GF_HIP(d_stats.alloc(8));
+  GF_HIP(hipMalloc((void**)&ix->d_slots, nslots * sizeof(uint64_t)));
+  GF_HIP(hipMalloc((void**)&ix->d_lin_base, lin_base.size() * sizeof(uint32_t)));
+  GF_HIP(hipMalloc((void**)&ix->d_lin_hi, lin_hi.size() * sizeof(uint32_t)));
+  GF_HIP(hipMalloc((void**)&ix->d_gene_len, glen.size() * sizeof(uint32_t)));
+  GF_HIP(hipMemset(ix->d_slots, 0, nslots * sizeof(uint64_t)));
+  GF_HIP(hipMemset(d_stats.p, 0, 8 * sizeof(unsigned long long)));
+  GF_HIP(hipMemcpy(d_cat.p, cat.data(), cat_bytes, hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(d_goff.p, gene_off.data(), gene_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(ix->d_lin_base, lin_base.data(), lin_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(ix->d_lin_hi, lin_hi.data(), lin_hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(ix->d_gene_len, glen.data(), glen.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+
+  GfGenes G;
+  G.cat = d_cat.p;
+  G.gene_off = d_goff.p;
+  G.lin_base = ix->d_lin_base;
+  G.total = (uint32_t)total;
+  G.n_genes = n_genes;
+
+  const int sweep_grid = (int)std::min<uint64_t>((nslots + 255) / 256, (uint64_t)ix->n_cus * 16);
+  unsigned long long stats[8] = {0};
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_COUNT>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
+                       ix->d_slots, nbuckets, (uint32_t*)nullptr);
+    GF_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(gf_k_classify_count, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
+  GF_HIP(hipGetLastError());
+  GF_HIP(hipMemcpy(stats, d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
+  const uint64_t n_dupe_sites = stats[5];
+  if (n_dupe_sites > (uint64_t)GF_DUPE_START_MASK)
+    return fail(GF_ERR_CAPACITY, "too many duplicated sites for the 26-bit duplicate index");
+  GF_HIP(hipMalloc((void**)&ix->d_dupes, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t)));
+  GF_HIP(hipMemset(ix->d_dupes, 0xFF, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t)));
+  hipLaunchKernelGGL(gf_k_classify_assign, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
+  GF_HIP(hipGetLastError());
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_FILL>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
+                       ix->d_slots, nbuckets, ix->d_dupes);
+    GF_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(gf_k_sort_dupes, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_dupes);
+  GF_HIP(hipGetLastError());
+  GF_HIP(hipDeviceSynchronize());
+
+  ix->table.slots = ix->d_slots;
+  ix->table.dupes = ix->d_dupes;
+  ix->table.lin_base = ix->d_lin_base;
+  ix->table.lin_hi = ix->d_lin_hi;
+  ix->table.gene_len = ix->d_gene_len;
+  ix->table.nbuckets = nbuckets;
+  ix->table.n_genes = n_genes;
+
+  gf_index_info& I = ix->info;
+  I.n_genes = n_genes;
+  I.total_bp = (int64_t)total;
+  I.n_sites = (int64_t)stats[0];
+  I.n_keys = (int64_t)stats[1];
+  I.n_unique = (int64_t)stats[2];
+  I.n_dupe_keys = (int64_t)stats[3];
+  I.n_high_keys = (int64_t)stats[4];
+  I.n_dupe_sites = (int64_t)stats[5];
+  I.n_buckets = nbuckets;
+  I.table_bytes = (int64_t)(nslots * sizeof(uint64_t) + std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t));
+  I.device = dev;
+  *out_index = ix.release();
+  return GF_OK;
+}
+
+void gf_index_free(gf_index* idx) {
+  if (!idx) return;
+  DeviceGuard guard(idx->device);
+  delete idx;
+}
+
+int gf_index_info_get(const gf_index* idx, gf_index_info* out) {
+  if (!idx || !out) return fail(GF_ERR_ARG, "null argument");
+  *out = idx->info;
+  return GF_OK;
+}
+
+int64_t gf_index_fusion_seq(const gf_index* idx, int32_t contig, char* out, int64_t cap) {
+  if (!idx || contig < 0 || (size_t)contig >= idx->fusion_seq.size()) return fail(GF_ERR_ARG, "bad contig");
+  const std::string& s = idx->fusion_seq[(size_t)contig];
+  if (out && cap > 0) memcpy(out, s.data(), (size_t)std::min<int64_t>(cap, (int64_t)s.size()));
+  return (int64_t)s.size();
+}
+
+int gf_index_lookup(const gf_index* idx, const uint32_t* kmers, int64_t n, int32_t* out_count,
+                    int16_t* out_contig, int32_t* out_position) {
+  if (!idx || n < 0 || (n > 0 && (!kmers || !out_count || !out_contig || !out_position)))
+    return fail(GF_ERR_ARG, "null argument");
+  if (n == 0) return GF_OK;
+  DeviceGuard guard(idx->device);
+  DevBuf<uint32_t> d_k;
+  DevBuf<int32_t> d_c, d_p;
+  DevBuf<int16_t> d_g;
+  GF_HIP(d_k.alloc((size_t)n));
+  GF_HIP(d_c.alloc((size_t)n));
+  GF_HIP(d_g.alloc((size_t)n * 5));
+  GF_HIP(d_p.alloc((size_t)n * 5));
+  GF_HIP(hipMemcpy(d_k.p, kmers, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  GF_HIP(hipMemset(d_g.p, 0, (size_t)n * 5 * sizeof(int16_t)));
+  GF_HIP(hipMemset(d_p.p, 0, (size_t)n * 5 * sizeof(int32_t)));
+  int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 8);
+  hipLaunchKernelGGL(gf_k_lookup, dim3(grid), dim3(256), 0, 0, idx->table, d_k.p, n, d_c.p, d_g.p, d_p.p);
+  GF_HIP(hipGetLastError());
+  GF_HIP(hipMemcpy(out_count, d_c.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  GF_HIP(hipMemcpy(out_contig, d_g.p, (size_t)n * 5 * sizeof(int16_t), hipMemcpyDeviceToHost));
+  GF_HIP(hipMemcpy(out_position, d_p.p, (size_t)n * 5 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return GF_OK;
+}
+
+int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
+                        int32_t max_read_len, void* d_counts, void* d_matches, void* stream) {
+  if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
+  if (n == 0) return GF_OK;
+  if (!d_offsets || !d_counts || !d_matches) return fail(GF_ERR_ARG, "null device pointer");
+  if (max_read_len > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "max_read_len exceeds GF_MAX_READ_LEN");
+  DeviceGuard guard(idx->device);
+  hipStream_t st = (hipStream_t)stream;
+  gf_index* mix = const_cast<gf_index*>(idx);
+  const bool prof = idx->profiling;
+  if (prof) {
+    std::lock_guard<std::mutex> lk(mix->prof_mu);
+    if (!mix->have_events) {
+      GF_HIP(hipEventCreate(&mix->ev0));
+      GF_HIP(hipEventCreate(&mix->ev1));
+      mix->have_events = true;
+    }
+    GF_HIP(hipEventRecord(mix->ev0, st));
+  }
+  const uint8_t* bases = (const uint8_t*)d_bases;
+  const int64_t* offsets = (const int64_t*)d_offsets;
+  uint8_t* counts = (uint8_t*)d_counts;
+  gf_seqmatch* matches = (gf_seqmatch*)d_matches;
+  // persistent grid: enough waves to fill every CU, reads interleaved across waves
+  if (max_read_len <= 256) {
+    constexpr int W = 4;
+    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 8 * 2);
+    hipLaunchKernelGGL((gf_k_map_reads<256, W>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets, n,
+                       counts, matches);
+  } else if (max_read_len <= 1024) {
+    constexpr int W = 4;
+    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 4 * 2);
+    hipLaunchKernelGGL((gf_k_map_reads<1024, W>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
+                       n, counts, matches);
+  } else {
+    constexpr int W = 2;
+    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 2 * 2);
+    hipLaunchKernelGGL((gf_k_map_reads<4096, W>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
+                       n, counts, matches);
+  }
+  GF_HIP(hipGetLastError());
+  if (prof) {
+    std::lock_guard<std::mutex> lk(mix->prof_mu);
+    GF_HIP(hipEventRecord(mix->ev1, st));
+    mix->recorded = true;
+  }
+  return GF_OK;
+}
+
+int64_t gf_compact_workspace_bytes(int64_t n) {
+  if (n < 0) return 0;
+  int64_t ntiles = (n + GF_CTILE - 1) / GF_CTILE;
+  return 64 + ntiles * (int64_t)(sizeof(uint32_t) + sizeof(int64_t)) + 16;
+}
+
+int gf_compact_hits_device(const gf_index* idx, const void* d_counts, const void* d_matches, int64_t n,
+                           int64_t read_id_base, void* d_hits, int64_t hits_cap, void* d_n_hits,
+                           void* d_workspace, void* stream) {
+  if (!idx || n < 0 || hits_cap < 0) return fail(GF_ERR_ARG, "bad argument");
+  if (!d_n_hits || !d_workspace) return fail(GF_ERR_ARG, "null device pointer");
+  DeviceGuard guard(idx->device);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ntiles = (n + GF_CTILE - 1) / GF_CTILE;
+  // workspace: [int64 tile_offsets[ntiles]] [uint32 tile_counts[ntiles]]
+  uintptr_t w = ((uintptr_t)d_workspace + 15) & ~(uintptr_t)15;
+  int64_t* tile_offsets = (int64_t*)w;
+  uint32_t* tile_counts = (uint32_t*)(w + (size_t)ntiles * sizeof(int64_t));
+  if (ntiles > 0) {
+    if (!d_counts || !d_matches || (hits_cap > 0 && !d_hits)) return fail(GF_ERR_ARG, "null device pointer");
+    hipLaunchKernelGGL(gf_k_compact_count, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st,
+                       (const uint8_t*)d_counts, n, tile_counts);
+    GF_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, tile_counts, ntiles, tile_offsets,
+                     (int64_t*)d_n_hits);
+  GF_HIP(hipGetLastError());
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(gf_k_compact_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st,
+                       (const uint8_t*)d_counts, (const gf_seqmatch*)d_matches, n, read_id_base, tile_offsets,
+                       (gf_hit*)d_hits, hits_cap);
+    GF_HIP(hipGetLastError());
+  }
+  return GF_OK;
+}
+
+// Host-buffer staging shared by gf_map_reads / gf_map_reads_hits.
+static int stage_and_map(const gf_index* idx, const char* bases, const int64_t* offsets, int64_t n,
+                         DevBuf<uint8_t>& d_counts, DevBuf<gf_seqmatch>& d_matches) {
+  if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
+  if (n > 0 && (!offsets)) return fail(GF_ERR_ARG, "offsets is null");
+  int64_t maxlen = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    int64_t l = offsets[r + 1] - offsets[r];
+    if (l < 0) return fail(GF_ERR_ARG, "offsets must be non-decreasing");
+    maxlen = std::max(maxlen, l);
+  }
+  if (maxlen > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "a read exceeds GF_MAX_READ_LEN");
+  const int64_t b0 = n > 0 ? offsets[0] : 0, b1 = n > 0 ? offsets[n] : 0;
+  if (b1 > b0 && !bases) return fail(GF_ERR_ARG, "bases is null");
+  DevBuf<uint8_t> d_bases;
+  DevBuf<int64_t> d_off;
+  GF_HIP(d_bases.alloc((size_t)(b1 - b0) + 16));
+  GF_HIP(d_off.alloc((size_t)n + 1));
+  GF_HIP(d_counts.alloc((size_t)n));
+  GF_HIP(d_matches.alloc((size_t)n * 2));
+  if (n == 0) return GF_OK;
+  // offsets are rebased so that the device buffer starts at the first read
+  std::vector<int64_t> rel((size_t)n + 1);
+  for (int64_t r = 0; r <= n; ++r) rel[(size_t)r] = offsets[r] - b0;
+  if (b1 > b0) GF_HIP(hipMemcpy(d_bases.p, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(d_off.p, rel.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  int rc = gf_map_reads_device(idx, d_bases.p, d_off.p, n, (int32_t)std::max<int64_t>(maxlen, 1), d_counts.p,
+                               d_matches.p, nullptr);
+  if (rc != GF_OK) return rc;
+  GF_HIP(hipDeviceSynchronize());
+  return GF_OK;
+}
+
+int gf_map_reads(const gf_index* idx, const char* bases, const int64_t* offsets, int64_t n,
+                 int32_t* out_counts, gf_seqmatch* out_matches) {
+  if (n > 0 && (!out_counts || !out_matches)) return fail(GF_ERR_ARG, "null output buffer");
+  if (!idx) return fail(GF_ERR_ARG, "null index");
+  DeviceGuard guard(idx->device);
+  DevBuf<uint8_t> d_counts;
+  DevBuf<gf_seqmatch> d_matches;
+  int rc = stage_and_map(idx, bases, offsets, n, d_counts, d_matches);
+  if (rc != GF_OK || n == 0) return rc;
+  std::vector<uint8_t> c8((size_t)n);
+  std::vector<gf_seqmatch> m((size_t)n * 2);
+  GF_HIP(hipMemcpy(c8.data(), d_counts.p, (size_t)n, hipMemcpyDeviceToHost));
+  GF_HIP(hipMemcpy(m.data(), d_matches.p, (size_t)n * 2 * sizeof(gf_seqmatch), hipMemcpyDeviceToHost));
+  for (int64_t r = 0; r < n; ++r) {
+    int c = c8[(size_t)r];
+    out_counts[r] = c;
+    for (int k = 0; k < c && k < 2; ++k) out_matches[2 * r + k] = m[(size_t)(2 * r + k)];
+  }
+  return GF_OK;
+}
+
+int gf_map_read(const gf_index* idx, const char* seq, int64_t len, gf_seqmatch out[2]) {
+  if (!out || len < 0) return fail(GF_ERR_ARG, "bad argument");
+  int64_t offsets[2] = {0, len};
+  int32_t count = 0;
+  gf_seqmatch m[2];
+  int rc = gf_map_reads(idx, seq, offsets, 1, &count, m);
+  if (rc != GF_OK) return rc;
+  for (int k = 0; k < count; ++k) out[k] = m[k];
+  return count;
+}
+
+int gf_map_reads_hits(const gf_index* idx, const char* bases, const int64_t* offsets, int64_t n,
+                      int64_t read_id_base, gf_hit* out_hits, int64_t cap, int64_t* out_n) {
+  if (!out_n || cap < 0 || (cap > 0 && !out_hits)) return fail(GF_ERR_ARG, "bad output argument");
+  if (!idx) return fail(GF_ERR_ARG, "null index");
+  *out_n = 0;
+  DeviceGuard guard(idx->device);
+  DevBuf<uint8_t> d_counts;
+  DevBuf<gf_seqmatch> d_matches;
+  int rc = stage_and_map(idx, bases, offsets, n, d_counts, d_matches);
+  if (rc != GF_OK || n == 0) return rc;
+  DevBuf<gf_hit> d_hits;
+  DevBuf<int64_t> d_total;
+  DevBuf<uint8_t> d_ws;
+  GF_HIP(d_hits.alloc((size_t)cap));
+  GF_HIP(d_total.alloc(1));
+  GF_HIP(d_ws.alloc((size_t)gf_compact_workspace_bytes(n)));
+  rc = gf_compact_hits_device(idx, d_counts.p, d_matches.p, n, read_id_base, d_hits.p, cap, d_total.p, d_ws.p,
+                              nullptr);
+  if (rc != GF_OK) return rc;
+  GF_HIP(hipDeviceSynchronize());
+  int64_t total = 0;
+  GF_HIP(hipMemcpy(&total, d_total.p, sizeof total, hipMemcpyDeviceToHost));
+  *out_n = total;
+  int64_t ncopy = std::min(total, cap);
+  if (ncopy > 0) GF_HIP(hipMemcpy(out_hits, d_hits.p, (size_t)ncopy * sizeof(gf_hit), hipMemcpyDeviceToHost));
+  return GF_OK;
+}
+
+// src/core/indexer.rs:541-608
+int gf_in_required_direction(const gf_seqmatch* m, int32_t n, const uint8_t* gene_reversed, int32_t n_genes) {
+  if (n < 2) return 0;
+  if (!m || !gene_reversed) return fail(GF_ERR_ARG, "null argument");
+  const gf_seqmatch* left = &m[0];
+  const gf_seqmatch* right = &m[1];
+  if (left->seq_start > right->seq_start) std::swap(left, right);
+  if (left->position > 0 && right->position > 0) return 1;
+  if (left->position < 0 && right->position < 0) return 0;
+  if (left->contig < 0 || left->contig >= n_genes || right->contig < 0 || right->contig >= n_genes)
+    return fail(GF_ERR_ARG, "contig out of range");
+  const bool lrev = gene_reversed[left->contig] != 0, rrev = gene_reversed[right->contig] != 0;
+  if (lrev && !rrev) return 0;
+  if (!lrev && rrev) return 1;
+  if (left->contig < right->contig) return 1;
+  // the reference's same-contig test compares left with itself (:598) and is never true
+  return 0;
+}
+
+int gf_set_profiling(gf_index* idx, int32_t on) {
+  if (!idx) return fail(GF_ERR_ARG, "null index");
+  idx->profiling = on != 0;
+  return GF_OK;
+}
+
+float gf_last_map_kernel_ms(gf_index* idx) {
+  if (!idx || !idx->have_events || !idx->recorded) return -1.0f;
+  DeviceGuard guard(idx->device);
+  std::lock_guard<std::mutex> lk(idx->prof_mu);
+  if (hipEventSynchronize(idx->ev1) != hipSuccess) return -1.0f;
+  float ms = -1.0f;
+  if (hipEventElapsedTime(&ms, idx->ev0, idx->ev1) != hipSuccess) return -1.0f;
+  return ms;
+}
+
+}  // extern "C"

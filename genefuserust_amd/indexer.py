@@ -1,0 +1,272 @@
+"""Host-side mirror of the reference's ``Indexer`` (src/core/indexer.rs:67-608)
+over the gfmatch C ABI.
+
+Same names, argument meaning and error behaviour as the Rust type so that the
+parity tests read like the reference's own: ``Indexer.with_loaded_ref(reference,
+fusions)``, ``make_index()``, ``map_read(read) -> [SeqMatch]``,
+``in_required_direction(mapping)``, ``m_fusion_seq``.  On top of that it offers
+the batch forms the GPU wants (``map_reads``, ``map_reads_device``).  All
+compute goes through libgfmatch.so; there is no Python or CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Mapping, NamedTuple, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import GfError, GfHit, GfIndexInfo, GfOptions, GfSeqMatch, HIT_DTYPE, SEQMATCH_DTYPE
+
+BytesLike = Union[bytes, bytearray, str]
+
+
+class GenePos(NamedTuple):
+    """src/core/common.rs:4-7"""
+    contig: int
+    position: int
+
+
+class SeqMatch(NamedTuple):
+    """src/core/indexer.rs:41-45"""
+    seq_start: int
+    seq_end: int
+    start_gp: GenePos
+
+    def __str__(self) -> str:  # indexer.rs:57-65
+        return "%d-%d|%d:%d" % (self.seq_start, self.seq_end, self.start_gp.contig, self.start_gp.position)
+
+
+@dataclass
+class Gene:
+    """The fields of src/core/gene.rs:16-23 that the Indexer reads."""
+    m_name: str
+    m_chr: str
+    m_start: int
+    m_end: int
+    m_reversed: bool = False
+
+    def is_reversed(self) -> bool:
+        return self.m_reversed
+
+
+@dataclass
+class Fusion:
+    """src/core/fusion.rs:14-16"""
+    m_gene: Gene
+
+    def is_reversed(self) -> bool:
+        return self.m_gene.is_reversed()
+
+
+def _as_bytes(s: BytesLike) -> bytes:
+    return s.encode("ascii") if isinstance(s, str) else bytes(s)
+
+
+def resolve_gene_slice(contigs: Mapping[str, BytesLike], gene: Gene) -> Optional[bytes]:
+    """indexer.rs:137-158: chromosome lookup by name, "chr"+name, name without
+    "chr"; then the raw CSV numbers used as a half-open byte range.  None when the
+    chromosome is missing (the gene then indexes nothing, :149-150).  Like the
+    reference's ``.get(a..b).unwrap()`` an out-of-range slice is an error."""
+    chr_ = gene.m_chr
+    if chr_ not in contigs:
+        if "chr" + chr_ in contigs:
+            chr_ = "chr" + chr_
+        elif chr_.replace("chr", "") in contigs:
+            chr_ = chr_.replace("chr", "")
+        else:
+            return None
+    seq = _as_bytes(contigs[chr_])
+    if not (0 <= gene.m_start <= gene.m_end <= len(seq)):
+        raise IndexError("gene %s: range %d..%d outside contig %s (len %d)"
+                         % (gene.m_name, gene.m_start, gene.m_end, chr_, len(seq)))
+    return seq[gene.m_start:gene.m_end]
+
+
+class Indexer:
+    """Drop-in for ``struct Indexer``; the index lives in HBM."""
+
+    def __init__(self, reference: Optional[Mapping[str, BytesLike]], fusions: Sequence[Fusion],
+                 device: int = -1):
+        # Indexer::with_loaded_ref (indexer.rs:100-112)
+        self.m_reference = reference
+        self.m_fusions = list(fusions)
+        self.m_fusion_seq: List[str] = []
+        self._device = device
+        self._h: Optional[C.c_void_p] = None
+        self._gene_slices: Optional[List[Optional[bytes]]] = None
+
+    with_loaded_ref = classmethod(lambda cls, reference, fusions, device=-1: cls(reference, fusions, device))
+
+    @classmethod
+    def from_gene_slices(cls, slices: Sequence[Optional[BytesLike]],
+                         reversed_flags: Optional[Sequence[bool]] = None, device: int = -1) -> "Indexer":
+        """Boundary form: gene slices already cut out (what gf_index_build takes)."""
+        fus = [Fusion(Gene("g%d" % i, "", 0, 0, bool(reversed_flags[i]) if reversed_flags else False))
+               for i in range(len(slices))]
+        ix = cls(None, fus, device)
+        ix._gene_slices = [None if s is None else _as_bytes(s) for s in slices]
+        return ix
+
+    def get_ref(self):
+        return self.m_reference
+
+    # -- make_index (indexer.rs:122-177) ------------------------------------
+    def make_index(self) -> None:
+        if self._gene_slices is None:
+            if self.m_reference is None:
+                return  # indexer.rs:123-125
+            self._gene_slices = [resolve_gene_slice(self.m_reference, f.m_gene) for f in self.m_fusions]
+        L = _lib.lib()
+        n = len(self._gene_slices)
+        keep = [s if s is not None else b"" for s in self._gene_slices]
+        arr = (C.c_char_p * max(n, 1))(*keep) if n else (C.c_char_p * 1)()
+        lens = (C.c_int64 * max(n, 1))(*[(-1 if s is None else len(s)) for s in self._gene_slices])
+        opts = GfOptions(device=self._device)
+        h = C.c_void_p()
+        _lib.check(L.gf_index_build(arr, lens, n, C.byref(opts), C.byref(h)))
+        self._free()
+        self._h = h
+        self.m_fusion_seq = []
+        for c in range(n):
+            ln = L.gf_index_fusion_seq(h, c, None, 0)
+            buf = C.create_string_buffer(max(int(ln), 1))
+            L.gf_index_fusion_seq(h, c, buf, ln)
+            self.m_fusion_seq.append(buf.raw[:ln].decode("latin-1"))
+
+    def _handle(self) -> C.c_void_p:
+        if self._h is None:
+            raise RuntimeError("make_index() has not been called")
+        return self._h
+
+    def info(self) -> Dict[str, int]:
+        out = GfIndexInfo()
+        _lib.check(_lib.lib().gf_index_info_get(self._handle(), C.byref(out)))
+        return {k: int(getattr(out, k)) for k, _ in GfIndexInfo._fields_ if k != "pad"}
+
+    def lookup(self, kmers: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """m_kmer_pos / m_dupe_list query for reference-coded k-mers (test aid)."""
+        k = np.ascontiguousarray(kmers, dtype=np.uint32)
+        n = k.size
+        cnt = np.zeros(n, dtype=np.int32)
+        ctg = np.zeros((n, 5), dtype=np.int16)
+        pos = np.zeros((n, 5), dtype=np.int32)
+        _lib.check(_lib.lib().gf_index_lookup(self._handle(), k.ctypes.data, n, cnt.ctypes.data,
+                                              ctg.ctypes.data, pos.ctypes.data))
+        return cnt, ctg, pos
+
+    # -- map_read (indexer.rs:252-538) --------------------------------------
+    def map_read(self, r: BytesLike) -> List[SeqMatch]:
+        seq = _as_bytes(getattr(r, "m_seq", r))
+        out = (GfSeqMatch * 2)()
+        n = _lib.check(_lib.lib().gf_map_read(self._handle(), seq, len(seq), out))
+        return [SeqMatch(out[k].seq_start, out[k].seq_end, GenePos(out[k].contig, out[k].position))
+                for k in range(n)]
+
+    def map_reads_packed(self, bases: np.ndarray, offsets: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """Batch form on host arrays: returns (counts int32[n], matches SEQMATCH_DTYPE[n,2])."""
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = o.size - 1
+        counts = np.zeros(max(n, 0), dtype=np.int32)
+        matches = np.zeros((max(n, 0), 2), dtype=SEQMATCH_DTYPE)
+        _lib.check(_lib.lib().gf_map_reads(self._handle(), b.ctypes.data if b.size else None, o.ctypes.data, n,
+                                           counts.ctypes.data, matches.ctypes.data))
+        return counts, matches
+
+    def map_reads(self, reads: Sequence[BytesLike]) -> List[List[SeqMatch]]:
+        from .synth import ragged_batch
+        bases, offsets = ragged_batch([_as_bytes(r) for r in reads])
+        counts, matches = self.map_reads_packed(bases, offsets)
+        return unpack_matches(counts, matches)
+
+    def map_reads_hits(self, bases: np.ndarray, offsets: np.ndarray, read_id_base: int = 0,
+                       cap: Optional[int] = None) -> np.ndarray:
+        """Only the non-empty results, ascending read id (HIT_DTYPE records)."""
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = o.size - 1
+        cap = n if cap is None else cap
+        hits = np.zeros(max(cap, 1), dtype=HIT_DTYPE)
+        total = C.c_int64(0)
+        _lib.check(_lib.lib().gf_map_reads_hits(self._handle(), b.ctypes.data if b.size else None,
+                                                o.ctypes.data, n, read_id_base, hits.ctypes.data, cap,
+                                                C.byref(total)))
+        return hits[:min(int(total.value), cap)]
+
+    # -- device-resident batch (torch tensors are only carriers of HBM pointers) --
+    def map_reads_device(self, bases, offsets, max_read_len: int, counts=None, matches=None, stream=None):
+        import torch
+        n = offsets.numel() - 1
+        assert bases.dtype == torch.uint8 and offsets.dtype == torch.int64 and bases.is_cuda and offsets.is_cuda
+        if counts is None:
+            counts = torch.empty(max(n, 1), dtype=torch.uint8, device=bases.device)
+        if matches is None:
+            matches = torch.empty((max(n, 1), 2, 4), dtype=torch.int32, device=bases.device)
+        st = torch.cuda.current_stream(bases.device).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().gf_map_reads_device(self._handle(), bases.data_ptr(), offsets.data_ptr(), n,
+                                                  int(max_read_len), counts.data_ptr(), matches.data_ptr(), st))
+        return counts, matches
+
+    def compact_hits_device(self, counts, matches, n: int, read_id_base: int = 0, cap: Optional[int] = None,
+                            stream=None):
+        """Ordered compaction on the device; returns (hits int64[cap, 6] view of gf_hit, n_hits tensor)."""
+        import torch
+        dev = counts.device
+        cap = n if cap is None else cap
+        hits = torch.empty((max(cap, 1), 6), dtype=torch.int64, device=dev)
+        n_hits = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = torch.empty(int(_lib.lib().gf_compact_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().gf_compact_hits_device(self._handle(), counts.data_ptr(), matches.data_ptr(), n,
+                                                     read_id_base, hits.data_ptr(), cap, n_hits.data_ptr(),
+                                                     ws.data_ptr(), st))
+        return hits, n_hits
+
+    # -- in_required_direction (indexer.rs:541-608) ---------------------------
+    def in_required_direction(self, mapping: Sequence[SeqMatch]) -> bool:
+        n = len(mapping)
+        arr = (GfSeqMatch * max(n, 1))()
+        for k, m in enumerate(mapping):
+            arr[k] = GfSeqMatch(m.seq_start, m.seq_end, m.start_gp.position, m.start_gp.contig, 0)
+        rev = np.array([f.is_reversed() for f in self.m_fusions] or [0], dtype=np.uint8)
+        return bool(_lib.check(_lib.lib().gf_in_required_direction(arr, n, rev.ctypes.data, len(self.m_fusions))))
+
+    def set_profiling(self, on: bool) -> None:
+        _lib.check(_lib.lib().gf_set_profiling(self._handle(), int(on)))
+
+    def last_map_kernel_ms(self) -> float:
+        return float(_lib.lib().gf_last_map_kernel_ms(self._handle()))
+
+    def _free(self) -> None:
+        if self._h is not None:
+            _lib.lib().gf_index_free(self._h)
+            self._h = None
+
+    def close(self) -> None:
+        self._free()
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+
+def unpack_matches(counts: np.ndarray, matches: np.ndarray) -> List[List[SeqMatch]]:
+    out: List[List[SeqMatch]] = []
+    for r in range(counts.size):
+        row = []
+        for k in range(int(counts[r])):
+            m = matches[r, k]
+            row.append(SeqMatch(int(m["seq_start"]), int(m["seq_end"]),
+                                GenePos(int(m["contig"]), int(m["position"]))))
+        out.append(row)
+    return out
+
+
+def hits_to_numpy(hits_i64) -> np.ndarray:
+    """torch int64[k, 6] view of gf_hit records -> structured numpy array."""
+    a = hits_i64.detach().cpu().numpy()
+    return a.view(HIT_DTYPE).reshape(-1)

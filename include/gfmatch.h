@@ -1,0 +1,170 @@
+/* gfmatch — MI355X-native k-mer seed matcher: C ABI.
+ *
+ * Drop-in boundary for the one hot path of Crispy13/GeneFuseRust: the `Indexer`
+ * of src/core/indexer.rs (index build + per-read seed mapping).  The reference
+ * has no FFI of its own; the seam is the Rust method set that `FusionMapper`
+ * uses.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference root).  INTEGRATION.md shows the
+ * Rust `extern "C"` block and the `Indexer` wrapper a maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, caller owns every buffer, no panics —
+ * functions return GF_OK (0) or a negative GF_ERR_* code and gf_last_error()
+ * holds a message for the calling thread.  There is no CPU fallback: every
+ * compute entry point fails with GF_ERR_NO_DEVICE when no HIP device is usable.
+ * Concurrent gf_map_* calls on one index are allowed (the index is read-only
+ * after gf_index_build, like `&self` in Indexer::map_read).
+ */
+#ifndef GFMATCH_H
+#define GFMATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF_OK 0
+#define GF_ERR_ARG (-1)           /* null pointer, negative size, bad offsets */
+#define GF_ERR_HIP (-2)           /* a HIP runtime call failed */
+#define GF_ERR_NO_DEVICE (-3)     /* no usable HIP device */
+#define GF_ERR_CAPACITY (-4)      /* gene set too large for the 29-bit site space */
+#define GF_ERR_READ_TOO_LONG (-5) /* a read exceeds GF_MAX_READ_LEN */
+
+/* Longest read accepted.  The reference cannot see reads above 1000 bases
+ * (src/core/fastq_reader.rs:27 caps a FASTQ line at 1000 bytes and panics
+ * beyond), merged pairs stay below 2000. */
+#define GF_MAX_READ_LEN 4096
+
+/* Marker written to out_counts for a read longer than the limit given to
+ * gf_map_reads_device (the host entry points return GF_ERR_READ_TOO_LONG). */
+#define GF_COUNT_TOO_LONG 255
+
+typedef struct gf_index gf_index; /* opaque; replaces `struct Indexer` (indexer.rs:67-78) */
+
+/* SeqMatch + GenePos flattened (indexer.rs:41-45, common.rs:4-7).
+ * [seq_start, seq_end] is the inclusive read interval; (contig, position) is
+ * start_gp: contig = index into the gene list, negative position = reverse strand. */
+typedef struct gf_seqmatch {
+  int32_t seq_start;
+  int32_t seq_end;
+  int32_t position;
+  int16_t contig;
+  int16_t pad;
+} gf_seqmatch;
+
+/* One read's non-empty result, as exchanged between ranks and handed to the
+ * host-side scoring (`FusionMapper::map_read`, fusion_mapper.rs:93-132). */
+typedef struct gf_hit {
+  int64_t read_id; /* read_id_base + index of the read in the batch */
+  int32_t n;       /* 1 or 2 valid entries in m[] (TOP first, then SECOND) */
+  int32_t pad;
+  gf_seqmatch m[2];
+} gf_hit;
+
+typedef struct gf_options {
+  int32_t device;        /* HIP device ordinal; -1 = the calling thread's current device */
+  int32_t reserved[7];   /* must be zero */
+} gf_options;
+
+typedef struct gf_index_info {
+  int64_t n_genes;
+  int64_t total_bp;       /* sum of gene lengths */
+  int64_t n_sites;        /* valid (key, site) pairs enumerated over both strands */
+  int64_t n_keys;         /* distinct k-mers = m_kmer_pos.len() */
+  int64_t n_unique;       /* keys with exactly one site */
+  int64_t n_dupe_keys;    /* keys with 2..5 sites (DUPE_NORMAL_LEVEL) */
+  int64_t n_high_keys;    /* keys with >= 6 sites (DUPE_HIGH_LEVEL) */
+  int64_t n_dupe_sites;   /* sites stored in duplicate lists */
+  int64_t n_buckets;      /* 64-byte buckets in the device table */
+  int64_t table_bytes;    /* device bytes: buckets + duplicate lists */
+  int32_t device;
+  int32_t pad;
+} gf_index_info;
+
+/* --- index lifetime --------------------------------------------------------
+ * gf_index_build replaces Indexer::new / Indexer::with_loaded_ref followed by
+ * Indexer::make_index (indexer.rs:81, :100, :122-177) from the point where each
+ * gene's slice has been cut out of its chromosome (indexer.rs:154-158):
+ * gene_seqs[c] points at gene_lens[c] raw bytes (any case; upper-cased inside,
+ * like :159).  gene_lens[c] < 0 marks a gene whose chromosome was not found
+ * (:149-150): nothing is indexed and its fusion sequence is "".
+ * Builds forward and reverse-complement sites, classifies keys into unique /
+ * 2..5 / >=6 (:179-241) and leaves the table resident in HBM. */
+int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32_t n_genes,
+                   const gf_options* opts, gf_index** out_index);
+void gf_index_free(gf_index* idx);
+int gf_index_info_get(const gf_index* idx, gf_index_info* out);
+
+/* Indexer.m_fusion_seq[c] (indexer.rs:77, :170; read by fusion_mapper.rs:230,
+ * :439-452): the upper-cased gene slice, kept on the host.  Returns its length
+ * (or a negative error) and copies min(cap, length) bytes to out when out != NULL. */
+int64_t gf_index_fusion_seq(const gf_index* idx, int32_t contig, char* out, int64_t cap);
+
+/* Test/diagnostic query of the device table: for each reference-coded k-mer
+ * (2 bits per base, first base most significant, A=0 T=1 C=2 G=3,
+ * indexer.rs:789-913) report what m_kmer_pos / m_dupe_list hold
+ * (indexer.rs:300-320): out_count[i] = 0 absent, -2 HIGH, else 1..5 sites
+ * written to out_contig[5*i..], out_position[5*i..] in ascending (contig,
+ * position) order.  Host buffers. */
+int gf_index_lookup(const gf_index* idx, const uint32_t* kmers, int64_t n, int32_t* out_count,
+                    int16_t* out_contig, int32_t* out_position);
+
+/* --- mapping ---------------------------------------------------------------
+ * gf_map_reads replaces the per-pack loop over Indexer::map_read
+ * (indexer.rs:252-538 called from fusion_mapper.rs:100 inside
+ * pescanner.rs:430-515): read r is bases[offsets[r] .. offsets[r+1]) (ASCII, not
+ * case-folded, like the reference).  out_counts[r] = len of the returned
+ * Vec<SeqMatch> (0..2); out_matches[2*r + k] its elements in order (TOP, SECOND).
+ * Entries beyond out_counts[r] are left untouched.  Host buffers; copies in,
+ * launches, copies out, synchronises. */
+int gf_map_reads(const gf_index* idx, const char* bases, const int64_t* offsets, int64_t n,
+                 int32_t* out_counts, gf_seqmatch* out_matches);
+
+/* Indexer::map_read for one read (indexer.rs:252): returns the number of
+ * SeqMatch written to out (0..2) or a negative error.  Same kernel, n = 1. */
+int gf_map_read(const gf_index* idx, const char* seq, int64_t len, gf_seqmatch out[2]);
+
+/* Same, host buffers in, only the non-empty results out, in read order:
+ * out_hits[0..*out_n) with read_id = read_id_base + r.  If more than cap reads
+ * hit, *out_n holds the total and only cap records are written. */
+int gf_map_reads_hits(const gf_index* idx, const char* bases, const int64_t* offsets, int64_t n,
+                      int64_t read_id_base, gf_hit* out_hits, int64_t cap, int64_t* out_n);
+
+/* Device-resident form (the measured path): every pointer is device memory on
+ * the index's device, `stream` is a hipStream_t (NULL = default stream), nothing
+ * is synchronised.  d_counts is uint8[n] (0..2, or GF_COUNT_TOO_LONG);
+ * d_matches is gf_seqmatch[2*n] (entries beyond the count untouched).
+ * max_read_len = upper bound of the read lengths in the batch (<= GF_MAX_READ_LEN);
+ * it selects the LDS footprint of the kernel; longer reads get GF_COUNT_TOO_LONG. */
+int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
+                        int32_t max_read_len, void* d_counts, void* d_matches, void* stream);
+
+/* Ordered compaction of the dense result (device): writes gf_hit records for the
+ * reads with count 1..2, ascending read index, to d_hits (capacity hits_cap
+ * records) and the total to *d_n_hits (int64 on device).  d_workspace must hold
+ * gf_compact_workspace_bytes(n) bytes. */
+int64_t gf_compact_workspace_bytes(int64_t n);
+int gf_compact_hits_device(const gf_index* idx, const void* d_counts, const void* d_matches,
+                           int64_t n, int64_t read_id_base, void* d_hits, int64_t hits_cap,
+                           void* d_n_hits, void* d_workspace, void* stream);
+
+/* Indexer::in_required_direction (indexer.rs:541-608), host logic.
+ * gene_reversed[c] = Fusion::is_reversed() of gene c (gene.rs:98-107).
+ * Returns 1/0, or a negative error. */
+int gf_in_required_direction(const gf_seqmatch* matches, int32_t n, const uint8_t* gene_reversed,
+                             int32_t n_genes);
+
+/* --- instrumentation -------------------------------------------------------
+ * With profiling on, gf_map_reads_device brackets its mapping kernel with HIP
+ * events on the launch stream; gf_last_map_kernel_ms synchronises on them and
+ * returns the duration of the most recent launch (negative if none). */
+int gf_set_profiling(gf_index* idx, int32_t on);
+float gf_last_map_kernel_ms(gf_index* idx);
+
+const char* gf_last_error(void);
+const char* gf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFMATCH_H */

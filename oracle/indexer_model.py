@@ -1,0 +1,188 @@
+"""ORACLE (second model) — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+
+A second, independently written model of the GeneFuseRust ``Indexer`` hot path,
+implemented from the prose specification in SURVEY.md Appendix A (not by
+transliterating oracle/indexer_oracle.cc): dict/Counter based, k-mers always
+computed from scratch, votes ranked with a sort, mask built as a windowed max.
+Its only purpose is to cross-check the C++ restatement: two independent
+restatements agreeing on the fixtures is the strongest pin available while the
+Rust reference cannot be run (no rustc/cargo in this pipeline).
+
+Pure-Python loops: small cases only.  Only tests/ may import this module.
+
+Reference lines restated (relative to /root/reference):
+  src/core/indexer.rs:122-250 (make_index, index_contig, fill_bloom_filter)
+  src/core/indexer.rs:252-538 (map_read), :616-679 (segment_mask)
+  src/core/indexer.rs:690-732, :789-913 (helpers), src/core/sequence.rs:22-60
+"""
+from __future__ import annotations
+
+from collections import Counter, defaultdict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+K = 16
+CODE = {"A": 0, "T": 1, "C": 2, "G": 3}  # indexer.rs:825-841
+COMP = {"A": "T", "a": "T", "T": "A", "t": "A", "C": "G", "c": "G", "G": "C", "g": "C"}
+
+HIGH = "HIGH"
+
+Site = Tuple[int, int]  # (contig, position)
+Match = Tuple[int, int, int, int]  # (seq_start, seq_end, contig, position)
+
+
+def kmer_at(s: str, i: int) -> Optional[int]:
+    """Appendix A: 2-bit pack of s[i:i+16], first base most significant; None if invalid."""
+    v = 0
+    for ch in s[i:i + K]:
+        c = CODE.get(ch)
+        if c is None:
+            return None
+        v = (v << 2) | c
+    return v
+
+
+def revcomp(s: str) -> str:
+    """sequence.rs:22-60 — anything outside ACGTacgt becomes N; output upper case."""
+    return "".join(COMP.get(ch, "N") for ch in reversed(s))
+
+
+def key64(contig: int, diag: int) -> int:
+    """indexer.rs:698-706: contig in the high word, position's 32 bit pattern in the low."""
+    return (contig << 32) | (diag & 0xFFFFFFFF)
+
+
+def unkey64(v: int) -> Site:
+    """indexer.rs:709-714."""
+    c = (v >> 32) & 0xFFFF
+    if c >= 0x8000:
+        c -= 0x10000
+    p = v & 0xFFFFFFFF
+    if p >= 0x80000000:
+        p -= 1 << 32
+    return c, p
+
+
+class IndexModel:
+    """Appendix A.1.  ``genes[c]`` is the raw gene slice or None (chromosome missing)."""
+
+    def __init__(self, genes: Sequence[Optional[str]]):
+        occ: Dict[int, List[Site]] = defaultdict(list)
+        self.fusion_seq: List[str] = []
+        for c, raw in enumerate(genes):
+            if raw is None:
+                self.fusion_seq.append("")
+                continue
+            s = raw.upper()
+            n = len(s)
+            self.fusion_seq.append(s)
+            # forward strand: windows 0 .. n-17 (the last window n-16 is not indexed)
+            for i in range(0, n - K):
+                k = kmer_at(s, i)
+                if k is not None:
+                    occ[k].append((c, i))
+            rc = revcomp(s)
+            for i in range(0, n - K):
+                k = kmer_at(rc, i)
+                if k is not None:
+                    occ[k].append((c, i + 1 - n))
+        # count 1 -> unique, 2..5 -> all kept, >= 6 -> HIGH (no sites)
+        self.table: Dict[int, object] = {}
+        for k, sites in occ.items():
+            self.table[k] = HIGH if len(sites) >= 6 else list(sites)
+
+    def sites(self, k: Optional[int]) -> List[Site]:
+        if k is None:
+            return []
+        v = self.table.get(k)
+        if v is None or v is HIGH:
+            return []
+        return v  # type: ignore[return-value]
+
+    # Appendix A.2
+    def map_read(self, read: str) -> List[Match]:
+        L = len(read)
+        votes: Counter = Counter()
+        for i in range(0, L - K + 1, 2):
+            for (c, p) in self.sites(kmer_at(read, i)):
+                votes[key64(c, p - i)] += 1
+        votes.pop(0, None)  # key 0 is invisible
+        ranked = sorted(votes.items(), key=lambda kv: (-kv[1], kv[0]))
+        gp1, count1 = ranked[0] if len(ranked) > 0 else (0, 0)
+        gp2, count2 = ranked[1] if len(ranked) > 1 else (0, 0)
+        if 2 * count1 < 40 or 2 * count2 < 20:
+            return []
+
+        wclass = [0] * max(0, L - K + 1)
+        for i in range(0, L - K + 1):
+            best = 0
+            for (c, p) in self.sites(kmer_at(read, i)):
+                d = key64(c, p - i)
+                if abs(d - gp1) <= 1:
+                    f = 3
+                elif abs(d - gp2) <= 1:
+                    f = 2
+                elif d == 0:
+                    f = 1
+                else:
+                    f = 0
+                best = max(best, f)
+            wclass[i] = best
+        mask = [0] * L
+        for j in range(L):
+            lo, hi = max(0, j - K + 1), min(j, L - K)
+            if lo <= hi:
+                mask[j] = max(wclass[lo:hi + 1])
+        if sum(1 for m in mask if m <= 1) > 10:
+            return []
+        return segment_mask(mask, unkey64(gp1), unkey64(gp2))
+
+
+def run_end(mask: Sequence[int], s: int, target: int) -> int:
+    """Appendix A.3 inner scan: inclusive end of the run that starts at s."""
+    L = len(mask)
+    end, g = s + 1, 0
+    while g < 10 and end + g < L:
+        m = mask[end + g]
+        if m > target:
+            break
+        if m == target:
+            end += g + 1
+            g = 0
+        else:
+            g += 1
+    return end - 1
+
+
+def segment_mask(mask: Sequence[int], gp1: Site, gp2: Site) -> List[Match]:
+    """Appendix A.3: every start s <= L-2 with mask[s]==target is tried; the first
+    longest run wins; it is emitted when end-start > 20."""
+    L = len(mask)
+    out: List[Match] = []
+    for target, gp in ((3, gp1), (2, gp2)):
+        best_s, best_e = -1, -1
+        for s in range(0, L - 1):
+            if mask[s] != target:
+                continue
+            e = run_end(mask, s, target)
+            if e - s > best_e - best_s:
+                best_s, best_e = s, e
+        if best_e - best_s > 20:
+            out.append((best_s, best_e, gp[0], gp[1]))
+    return out
+
+
+def in_required_direction(m: Sequence[Match], reversed_flags: Sequence[bool]) -> bool:
+    """indexer.rs:541-608 (with the left-vs-left comparison that is always false)."""
+    if len(m) < 2:
+        return False
+    left, right = (m[0], m[1]) if m[0][0] <= m[1][0] else (m[1], m[0])
+    if left[3] > 0 and right[3] > 0:
+        return True
+    if left[3] < 0 and right[3] < 0:
+        return False
+    lrev, rrev = bool(reversed_flags[left[2]]), bool(reversed_flags[right[2]])
+    if lrev and not rrev:
+        return False
+    if not lrev and rrev:
+        return True
+    return left[2] < right[2]
