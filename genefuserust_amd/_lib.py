@@ -67,6 +67,16 @@ def lib() -> C.CDLL:
         raise ImportError(
             "libgfmatch.so not found at %s — build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). gfmatch has no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  If
+    # libgfmatch.so were loaded first it would pull /opt/rocm's copy in, torch would
+    # then load its own, and the second runtime to initialise finds no device.
+    # Importing torch first makes the loader resolve our NEEDED libamdhip64.so.7 to
+    # the copy already in the process.  (A C/C++/Rust host without torch simply uses
+    # the system runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.gf_last_error.restype = C.c_char_p

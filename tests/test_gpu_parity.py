@@ -1,0 +1,232 @@
+"""Parity of the HIP path (through the C ABI) with the oracle — needs an MI355X.
+
+Bit-exact bar: identical SeqMatch lists (values and order) for every read,
+identical index content for every k-mer.  Nothing here reads /root/reference.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import branch_genes, branch_reads, matches_to_tuples, rand_seq, rc
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "branch_cases.json")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return json.load(open(GOLDEN))
+
+
+@pytest.fixture(scope="module")
+def branch_index(gpu_device, golden):
+    from genefuserust_amd import Indexer
+    genes = [None if x is None else x.encode() for x in golden["genes"]]
+    ix = Indexer.from_gene_slices(genes, golden["reversed"])
+    ix.make_index()
+    yield ix
+    ix.close()
+
+
+def _compare_reads(ix, ox, reads, label=""):
+    from genefuserust_amd.synth import ragged_batch
+    bases, offsets = ragged_batch(reads)
+    counts, matches = ix.map_reads_packed(bases, offsets)
+    ocounts, omatches = ox.map_reads_packed(bases, offsets, threads=8)
+    got = matches_to_tuples(counts, matches)
+    want = matches_to_tuples(ocounts, omatches)
+    bad = [r for r in range(len(reads)) if got[r] != want[r]]
+    assert not bad, "%s: %d/%d reads differ, first %d: got %s want %s read %r" % (
+        label, len(bad), len(reads), bad[0], got[bad[0]], want[bad[0]], reads[bad[0]])
+    return sum(1 for w in want if w)
+
+
+def test_index_stats_and_fusion_seq(branch_index, golden, oracle):
+    info = branch_index.info()
+    genes = [None if x is None else x.encode() for x in golden["genes"]]
+    assert info["n_genes"] == len(genes)
+    assert info["n_keys"] == golden["stats"]["n_keys"]
+    assert info["n_high_keys"] == golden["stats"]["n_high_keys"]
+    assert info["n_unique"] == golden["stats"]["m_unique_pos"]
+    # m_dupe_pos counts keys that ever became NORMAL dupes, HIGH ones included
+    assert info["n_dupe_keys"] + info["n_high_keys"] == golden["stats"]["m_dupe_pos"]
+    ox = oracle.OracleIndexer(genes)
+    assert branch_index.m_fusion_seq == [ox.fusion_seq(c) for c in range(len(genes))]
+    assert branch_index.m_fusion_seq[2] == golden["genes"][2].upper()
+    assert branch_index.m_fusion_seq[3] == ""
+
+
+def test_index_content_every_key(branch_index, golden):
+    keys = np.array([k for k, _, _ in golden["index"]], dtype=np.uint32)
+    cnt, ctg, pos = branch_index.lookup(keys)
+    for j, (k, n, sites) in enumerate(golden["index"]):
+        assert cnt[j] == n, (k, cnt[j], n)
+        if n > 0:
+            assert [(int(ctg[j, t]), int(pos[j, t])) for t in range(n)] == [tuple(s) for s in sites], k
+    # absent k-mers stay absent (exact membership, like the reference's 2^32-bit bitmap)
+    rng = np.random.default_rng(5)
+    present = set(int(k) for k in keys)
+    absent = np.array([k for k in rng.integers(0, 1 << 32, size=20000, dtype=np.uint64) if int(k) not in present],
+                      dtype=np.uint32)
+    cnt, _, _ = branch_index.lookup(absent)
+    assert not cnt.any()
+    # neighbours of present keys (one base changed) are the likeliest false positives
+    near = np.array([k ^ (1 << int(b)) for k in list(present)[:3000] for b in (0, 7, 31)], dtype=np.uint32)
+    near = np.array([k for k in near if int(k) not in present], dtype=np.uint32)
+    cnt, _, _ = branch_index.lookup(near)
+    assert not cnt.any()
+
+
+def test_map_golden_cases(branch_index, golden):
+    reads = [c["read"].encode() for c in golden["cases"]]
+    got = branch_index.map_reads(reads)
+    for c, g in zip(golden["cases"], got):
+        flat = [(m.seq_start, m.seq_end, m.start_gp.contig, m.start_gp.position) for m in g]
+        assert flat == [tuple(m) for m in c["expect"]], c["label"]
+
+
+def test_map_read_single_call(branch_index, golden):
+    from genefuserust_amd import GenePos, SeqMatch
+    for c in golden["cases"][:48]:
+        got = branch_index.map_read(c["read"])
+        assert got == [SeqMatch(a, b, GenePos(ct, p)) for a, b, ct, p in c["expect"]], c["label"]
+
+
+def test_in_required_direction_on_golden(branch_index, golden, oracle):
+    reads = [c["read"].encode() for c in golden["cases"]]
+    for c, g in zip(golden["cases"], branch_index.map_reads(reads)):
+        want = oracle.in_required_direction([tuple(m) for m in c["expect"]], golden["reversed"])
+        assert branch_index.in_required_direction(g) == want, c["label"]
+
+
+def test_kernel_variants_and_alignment(branch_index, golden):
+    """The three LDS footprints (<=256, <=1024, <=4096) and every byte alignment of
+    the read start give the same answer."""
+    import torch
+    from genefuserust_amd.synth import ragged_batch
+    reads = [c["read"].encode() for c in golden["cases"]]
+    want = [[tuple(m) for m in c["expect"]] for c in golden["cases"]]
+    for pad in (0, 1, 2, 3):
+        bases, offsets = ragged_batch(reads)
+        bases = np.concatenate([np.frombuffer(b"G" * pad, dtype=np.uint8), bases])
+        offsets = offsets + pad
+        d_b = torch.from_numpy(bases).cuda()
+        d_o = torch.from_numpy(offsets).cuda()
+        for lcap in (270, 1024, 4096):
+            counts, matches = branch_index.map_reads_device(d_b, d_o, lcap)
+            torch.cuda.synchronize()
+            c = counts.cpu().numpy().astype(np.int32)[:len(reads)]
+            m = matches.cpu().numpy().view(np.dtype([("seq_start", "<i4"), ("seq_end", "<i4"),
+                                                    ("position", "<i4"), ("contig", "<i2"), ("pad", "<i2")]))
+            m = m.reshape(-1, 2)[:len(reads)]
+            assert matches_to_tuples(c, m) == want, (pad, lcap)
+    # a batch limit below the longest read marks that read instead of mapping it
+    bases, offsets = ragged_batch(reads)
+    counts, _ = branch_index.map_reads_device(torch.from_numpy(bases).cuda(), torch.from_numpy(offsets).cuda(), 256)
+    c = counts.cpu().numpy()
+    lens = np.diff(offsets)
+    assert (c[lens > 256] == 255).all() and (c[lens <= 256] <= 2).all()
+
+
+def test_hits_compaction_is_ordered_and_complete(branch_index, golden):
+    from genefuserust_amd.synth import ragged_batch
+    reads = [c["read"].encode() for c in golden["cases"]] * 40  # > 2 compaction tiles
+    bases, offsets = ragged_batch(reads)
+    counts, matches = branch_index.map_reads_packed(bases, offsets)
+    hits = branch_index.map_reads_hits(bases, offsets, read_id_base=1000)
+    idx = np.nonzero(counts)[0]
+    assert hits["read_id"].tolist() == (idx + 1000).tolist()
+    assert hits["n"].tolist() == counts[idx].tolist()
+    for h, r in zip(hits, idx):
+        for k in range(int(h["n"])):
+            assert h["m"][k] == matches[r, k]
+    # capacity smaller than the number of hits: total still reported, prefix written
+    few = branch_index.map_reads_hits(bases, offsets, cap=5)
+    assert few["read_id"].tolist() == idx[:5].tolist()
+
+
+def test_edge_batches(branch_index, gpu_device, oracle):
+    from genefuserust_amd import Indexer, _lib
+    # empty batch
+    counts, matches = branch_index.map_reads_packed(np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    assert counts.size == 0
+    # batch of only empty / tiny reads
+    assert branch_index.map_reads([b"", b"A", b"ACGT" * 4, b""]) == [[], [], [], []]
+    # too long
+    with pytest.raises(_lib.GfError) as e:
+        branch_index.map_read(b"A" * 5000)
+    assert e.value.code == _lib.GF_ERR_READ_TOO_LONG
+    # BASELINE config 1 plumbing: every gene unresolved -> empty index -> every read []
+    ix = Indexer.from_gene_slices([None, None, None, None])
+    ix.make_index()
+    assert ix.info()["n_keys"] == 0 and ix.m_fusion_seq == ["", "", "", ""]
+    r1 = (b"CATCACACACCTTGACTGGTCCCCAGACAACAAGTATATAATGTCTAACTCGGGAGACTATGAAATATTGTACTGTAAGTATGAATGATT"
+          b"TTATATATATATATATATGCTATGATTATATTTATATATATAATAATTATTTTCCATATAT")
+    assert ix.map_reads([r1, rc(r1), r1[:148]]) == [[], [], []]
+    ix.close()
+    # no genes at all
+    ix = Indexer.from_gene_slices([])
+    ix.make_index()
+    assert ix.map_reads([r1]) == [[]]
+    ix.close()
+
+
+def test_with_loaded_ref_constructor(gpu_device, oracle):
+    """Indexer::with_loaded_ref + make_index chromosome resolution and slicing
+    (indexer.rs:137-159): exact name, "chr"+name, name without "chr", missing."""
+    from genefuserust_amd import Fusion, Gene, Indexer
+    rng = np.random.default_rng(21)
+    ref = {"chr2": rand_seq(rng, 4000), "7": rand_seq(rng, 3000), "chrX": rand_seq(rng, 2500).lower()}
+    fus = [Fusion(Gene("A", "chr2", 100, 1900)), Fusion(Gene("B", "chr7", 50, 1500, True)),
+           Fusion(Gene("C", "X", 10, 2000)), Fusion(Gene("D", "chr9", 1, 1000))]
+    ix = Indexer.with_loaded_ref(ref, fus)
+    ix.make_index()
+    slices = [ref["chr2"][100:1900], ref["7"][50:1500], ref["chrX"][10:2000], None]
+    ox = oracle.OracleIndexer(slices)
+    assert ix.m_fusion_seq == [ox.fusion_seq(c) for c in range(4)]
+    assert ix.m_fusion_seq[2] == ref["chrX"][10:2000].decode().upper() and ix.m_fusion_seq[3] == ""
+    up = [s.upper() if s else s for s in slices]
+    reads = [up[0][500:575] + up[1][700:775], up[2][300:380] + up[0][1000:1070], rc(up[1][200:275] + up[2][900:975])]
+    _compare_reads(ix, ox, reads, "with_loaded_ref")
+    ix.close()
+
+
+@pytest.mark.parametrize("shape,scale,n_reads", [("IDX-T", 0.02, 60000), ("IDX-C", 0.004, 60000)])
+def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads):
+    """Repeat-rich synthetic genes (2 % repeat family, N bases) and a junction-heavy
+    read mix: every read's SeqMatch list equals the oracle's."""
+    from genefuserust_amd import Indexer
+    from genefuserust_amd import synth
+    genes = synth.make_geneset(shape, scale=scale)
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    ox = oracle.OracleIndexer(genes.seqs)
+    info = ix.info()
+    st = ox.stats()
+    assert (info["n_keys"], info["n_high_keys"], info["n_unique"]) == (st["n_keys"], st["n_high_keys"], st["m_unique_pos"])
+    keys = ox.keys()[::97]
+    cnt, ctg, pos = ix.lookup(keys.astype(np.uint32))
+    for j, k in enumerate(keys):
+        n, sites = ox.lookup(int(k))
+        assert cnt[j] == n
+        if n > 0:
+            assert [(int(ctg[j, t]), int(pos[j, t])) for t in range(n)] == sites
+    synth.MIXES["TEST"] = (0.2, 0.5, 0.3)
+    total_hits = 0
+    for L in (150, 100, 251):
+        rb = synth.make_reads(genes, n_reads // 3, read_len=L, mix="TEST", seed=77 + L)
+        bases = rb.bases.numpy()
+        offsets = rb.offsets.numpy()
+        counts, matches = ix.map_reads_packed(bases, offsets)
+        ocounts, omatches = ox.map_reads_packed(bases, offsets, threads=8)
+        assert (counts == ocounts).all(), np.nonzero(counts != ocounts)[0][:10]
+        nz = counts > 0
+        assert (matches[nz, 0] == omatches[nz, 0]).all()
+        two = counts == 2
+        assert (matches[two, 1] == omatches[two, 1]).all()
+        total_hits += int(nz.sum())
+    assert total_hits > 1000  # the mix really exercises the second pass
+    ix.close()
