@@ -230,3 +230,17 @@ def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads):
         total_hits += int(nz.sum())
     assert total_hits > 1000  # the mix really exercises the second pass
     ix.close()
+
+
+def test_cpp_host_mirror(gpu_device, tmp_path):
+    """include/gf_indexer.hpp (the compiled-language host side above the C ABI):
+    planted-fusion known answer through the C++ Indexer mirror."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_indexer")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "test_indexer.cpp"), "-o", exe,
+                    "-L" + os.path.join(root, "genefuserust_amd"), "-lgfmatch",
+                    "-Wl,-rpath," + os.path.join(root, "genefuserust_amd")], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun) from the repo root:
+#   bash tools/profile_gpu.sh <tag>
+# 1) rocprofv3 --kernel-trace --stats of the default bench command
+# 2) separate --pmc passes for HBM traffic (FETCH_SIZE / WRITE_SIZE cannot share a pass)
+# Summaries land in gpurun_out/prof_<tag>/ ; copy what is to be judged into profiles/.
+set -o pipefail
+TAG=${1:-r01}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity"
+echo "== kernel trace ==" 
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.log 2>&1 || { echo trace failed; tail -20 $OUT/trace_bench.log; exit 1; }
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+  name=$(echo $pmc | tr ' ' '_' | cut -c1-40)
+  echo "== pmc $pmc =="
+  rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_$name -o pmc -- $BENCH > $OUT/pmc_${name}.log 2>&1 || { echo "pmc $pmc failed"; tail -5 $OUT/pmc_${name}.log; }
+done
+cd $REPO
+python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt

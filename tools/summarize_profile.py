@@ -1,0 +1,42 @@
+"""Condense a tools/profile_gpu.sh output directory into a short text summary
+(per-kernel stats + per-launch PMC sums for the mapping kernel)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+print("# rocprofv3 summary for", os.path.basename(out))
+for f in find("trace/**/*kernel_stats.csv"):
+    print("\n## kernel stats (%s)" % os.path.relpath(f, out))
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:12]:
+        print("%-70s calls=%-5s total_ns=%-14s avg_ns=%-12s pct=%s" % (
+            r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
+for f in find("trace/**/*kernel_trace.csv"):
+    rows = list(csv.DictReader(open(f)))
+    ks = [r for r in rows if "gf_k_map_reads" in r.get("Kernel_Name", "")]
+    if ks:
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ks]
+        r0 = ks[0]
+        print("\n## gf_k_map_reads dispatches: n=%d avg=%.3f ms min=%.3f max=%.3f  VGPR=%s SGPR=%s LDS=%s grid=%s wg=%s" % (
+            len(d), sum(d) / len(d) / 1e6, min(d) / 1e6, max(d) / 1e6, r0.get("VGPR_Count"), r0.get("SGPR_Count"),
+            r0.get("LDS_Block_Size"), r0.get("Grid_Size"), r0.get("Workgroup_Size")))
+for f in find("pmc_*/**/*counter_collection.csv"):
+    rows = list(csv.DictReader(open(f)))
+    acc = defaultdict(list)
+    for r in rows:
+        if "gf_k_map_reads" in r.get("Kernel_Name", ""):
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if acc:
+        print("\n## pmc (%s), per gf_k_map_reads launch (mean over %d launches)" % (
+            os.path.relpath(f, out).split(os.sep)[0], len(next(iter(acc.values())))))
+        for k, v in acc.items():
+            print("  %-28s %.6g" % (k, sum(v) / len(v)))
