@@ -244,3 +244,67 @@ def test_cpp_host_mirror(gpu_device, tmp_path):
                     "-Wl,-rpath," + os.path.join(root, "genefuserust_amd")], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+def test_full_size_properties(gpu_device, oracle):
+    """BASELINE configs[1] at full size (20 M reads of 150 bp vs the druggable-shaped
+    index), checked through size-independent properties:
+      * every read the GPU reports segments for is re-mapped by the oracle (identical),
+        and so is a 100 K sample of the reads it reports nothing for;
+      * order independence: the same reads in reversed order give the reversed result
+        (no cross-read interference), compared as a checksum of per-read checksums;
+      * compaction: hit list = exactly the non-zero counts, ascending;
+      * a second launch is bit-identical (determinism)."""
+    import torch
+    from genefuserust_amd import Indexer, synth
+    from genefuserust_amd.indexer import hits_to_numpy
+    n, L = 20_000_000, 150
+    genes = synth.make_geneset("IDX-D")
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    ox = oracle.OracleIndexer(genes.seqs)
+    st, info = ox.stats(), ix.info()
+    assert (info["n_keys"], info["n_high_keys"], info["n_unique"]) == (st["n_keys"], st["n_high_keys"], st["m_unique_pos"])
+    rb = synth.make_reads(genes, n, read_len=L, mix="PANEL", seed=4242, device="cuda")
+    counts, matches = ix.map_reads_device(rb.bases, rb.offsets, L)
+    torch.cuda.synchronize()
+    assert int((counts > 2).sum()) == 0
+    hit_idx = torch.nonzero(counts).flatten()
+    assert 5_000 < hit_idx.numel() < 200_000
+    # oracle on all hits + a sample of non-hits
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    sample = torch.randint(0, n, (100_000,), device="cuda", generator=gen)
+    sel = torch.unique(torch.cat([hit_idx, sample]))
+    reads2d = rb.bases.view(n, L)
+    sub = reads2d[sel].contiguous().cpu().numpy().reshape(-1)
+    offs = np.arange(sel.numel() + 1, dtype=np.int64) * L
+    oc, om = ox.map_reads_packed(sub, offs, threads=16)
+    gc = counts[sel].cpu().numpy().astype(np.int32)
+    gm = matches[sel].cpu().numpy().view(om.dtype).reshape(-1, 2)
+    assert (gc == oc).all(), "count mismatch at %s" % sel.cpu().numpy()[np.nonzero(gc != oc)[0][:5]]
+    assert (gm[oc > 0, 0] == om[oc > 0, 0]).all() and (gm[oc == 2, 1] == om[oc == 2, 1]).all()
+    assert int((oc == 2).sum()) > 1000
+    # checksum of per-read checksums, order independence, determinism
+    def digest(c, m):
+        mm = m.view(-1, 8).to(torch.int64)
+        valid1 = (c >= 1).to(torch.int64)[:, None]
+        valid2 = (c == 2).to(torch.int64)[:, None]
+        w = torch.tensor([3, 5, 7, 11], dtype=torch.int64, device=c.device)
+        per = c.to(torch.int64) * 1000003 + ((mm[:, :4] * w) * valid1).sum(1) + ((mm[:, 4:] * w * 13) * valid2).sum(1)
+        return per
+    d1 = digest(counts, matches)
+    c2, m2 = ix.map_reads_device(rb.bases, rb.offsets, L)
+    torch.cuda.synchronize()
+    assert torch.equal(digest(c2, m2), d1)
+    rev_bases = reads2d.flip(0).contiguous().view(-1)
+    c3, m3 = ix.map_reads_device(rev_bases, rb.offsets, L)
+    torch.cuda.synchronize()
+    assert torch.equal(digest(c3, m3).flip(0), d1)
+    # compaction
+    hits, n_hits = ix.compact_hits_device(counts, matches, n, read_id_base=7, cap=hit_idx.numel() + 10)
+    torch.cuda.synchronize()
+    h = hits_to_numpy(hits[: int(n_hits.item())])
+    assert int(n_hits.item()) == hit_idx.numel()
+    assert (h["read_id"] == hit_idx.cpu().numpy() + 7).all()
+    assert (h["n"] == counts[hit_idx].cpu().numpy()).all()
+    ix.close()
