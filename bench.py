@@ -65,6 +65,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="first-pass producer: 0 seed+verify (default), 1 probe-all")
     args = ap.parse_args()
 
     import numpy as np
@@ -103,6 +104,7 @@ def main() -> None:
     ix.make_index()
     torch.cuda.synchronize()
     t_index = time.time() - t0
+    ix.set_map_variant(args.variant)
     info = ix.info()
     reads = synth.make_reads(genes, n, read_len=L, mix=args.mix, seed=20240116 + rank, device=str(dev))
     counts = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -187,7 +189,8 @@ def main() -> None:
                 traffic = None
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": "gf_k_map_reads<256,4>",
+            "kernel": "gf_k_map_reads<256,4,%d> (%s first pass)" % (1 - args.variant,
+                                                                       "probe-all" if args.variant else "seed+verify"),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

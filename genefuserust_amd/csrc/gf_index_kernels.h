@@ -152,6 +152,73 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_sites(GfGenes G, 
   }
 }
 
+// After FILL: publish the 2-bit packed genes (g2) and the per-window uniqueness bits
+// (uf, ur) used by the mapping kernel's diagonal verification.  Same tiling as
+// gf_k_index_sites; every word of the tile is written (no atomics: one wave owns 64
+// consecutive windows = two whole words).
+__global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_ubits(GfGenes G, uint64_t* slots,
+                                                                     uint32_t nbuckets,
+                                                                     uint32_t* __restrict__ g2,
+                                                                     uint32_t* __restrict__ uf,
+                                                                     uint32_t* __restrict__ ur) {
+  __shared__ uint32_t s_codes[GF_TILE_BASES / 16 + 2];
+  __shared__ uint32_t s_inv[GF_TILE_BASES / 32 + 2];
+  const uint32_t t0 = blockIdx.x * GF_TILE_BASES;
+  const int tid = threadIdx.x;
+  for (int ch = tid; ch < GF_TILE_BASES / 16 + 1; ch += GF_INDEX_THREADS) {
+    uint4 q = *(const uint4*)(G.cat + (size_t)t0 + 16u * ch);
+    uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+    gf_convert4(q.x, c0, i0);
+    gf_convert4(q.y, c1, i1);
+    gf_convert4(q.z, c2, i2);
+    gf_convert4(q.w, c3, i3);
+    uint32_t w = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+    s_codes[ch] = w;
+    if (ch < GF_TILE_BASES / 16) g2[t0 / 16 + ch] = w;
+    ((uint16_t*)s_inv)[ch] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+  }
+  if (tid == 0) {
+    s_codes[GF_TILE_BASES / 16 + 1] = 0;
+    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 1] = 0xFFFF;
+    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 2] = 0xFFFF;
+    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 3] = 0xFFFF;
+  }
+  __syncthreads();
+  for (int l = tid; l < GF_TILE_BASES; l += GF_INDEX_THREADS) {  // uniform trip count
+    const uint32_t g = t0 + (uint32_t)l;
+    bool u_f = false, u_r = false;
+    if (g < G.total && !gf_flags16(s_inv[l >> 5], s_inv[(l >> 5) + 1], (uint32_t)l)) {
+      int lo = 0, hi = G.n_genes;
+      while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (G.gene_off[mid] <= g) lo = mid; else hi = mid;
+      }
+      const uint32_t f = g - G.gene_off[lo];
+      const uint32_t len = G.gene_off[lo + 1] - G.gene_off[lo];
+      if (f + GF_KMER <= len) {
+        const uint32_t key = gf_window(s_codes[l >> 4], s_codes[(l >> 4) + 1], (uint32_t)l);
+        if (f + GF_KMER < len) {
+          const uint64_t* s = gf_find_slot(slots, nbuckets, key);
+          u_f = s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE;
+        }
+        if (f >= 1) {
+          const uint64_t* s = gf_find_slot(slots, nbuckets, gf_revcomp_key(key));
+          u_r = s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE;
+        }
+      }
+    }
+    const uint64_t mf = __ballot(u_f), mr = __ballot(u_r);
+    const int lane = tid & 63;
+    if (lane == 0) {
+      uf[g >> 5] = (uint32_t)mf;
+      ur[g >> 5] = (uint32_t)mr;
+    } else if (lane == 32) {
+      uf[g >> 5] = (uint32_t)(mf >> 32);
+      ur[g >> 5] = (uint32_t)(mr >> 32);
+    }
+  }
+}
+
 // stats[0]=n_sites [1]=n_keys [2]=n_unique [3]=n_dupe_keys [4]=n_high [5]=n_dupe_sites
 // [6]=dupes cursor (used by the assign pass)
 __global__ void gf_k_classify_count(const uint64_t* slots, uint64_t nslots,

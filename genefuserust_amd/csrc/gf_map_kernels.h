@@ -13,12 +13,31 @@
 // wave-uniform.  Per read the wave
 //   1. loads the read's bytes with coalesced dword loads, converts them once to a
 //      2-bit stream + invalid-bit stream in LDS;
-//   2. cuts its windows out of LDS (lane = window), probes one 64-byte bucket of
-//      the HBM/Infinity-Cache resident table per window;
-//   3. compacts the votes into an LDS list with ballot + mbcnt prefix sums and
-//      counts equal diagonals by repeated ballot ("peel").
+//   2. produces the first-pass vote list in LDS (two interchangeable producers,
+//      see "first pass" below);
+//   3. counts equal diagonals by repeated ballot ("peel"), ranks the top two;
+//   4. survivors only: second pass, mask, segment_mask.
 // Votes are 32-bit site codes (gf_table.h); only diagonals with >= 10 votes are
 // decoded to (contig, position) — nothing smaller can survive the gate.
+//
+// First pass, producer A ("probe all", any read length): lane = window, one
+// 64-byte bucket probe of the HBM/Infinity-Cache resident table per window.
+// The chip serves ~56 G such L2-missing requests per second whatever their size
+// (tools/mb_gather.hip), which is what bounds this producer.
+//
+// First pass, producer B ("seed + verify", reads up to 256 bases): exact, but
+// spends far fewer L2-missing requests:
+//   * 4 seed windows are probed; every UNIQUE seed hit names a candidate diagonal;
+//   * each candidate is verified against the genes themselves: window i is
+//     *verified* when its 16 bases equal the gene's window on that diagonal and that
+//     gene window's key is flagged unique in the index (uf/ur bits) — then the table
+//     would return exactly that one site, i.e. exactly one vote for the candidate,
+//     so the probe is skipped.  One diagonal costs ~3 cache lines instead of 68;
+//   * bound check: a diagonal can collect at most one vote per window, so with U
+//     windows still unknown the best two counts are at most v1+U and v2+U; if
+//     v1+U < 20 or v2+U < 10 the read cannot pass the gate -> [] without probing;
+//   * otherwise the unknown windows are probed like producer A, all but the last 19
+//     first: when no window has produced a vote by then, count1 <= 19 -> [].
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -130,219 +149,472 @@ struct GfMapSmem {
   } u;
 };
 
-template <int LCAP, int WAVES>
+// ---- 1'. the same from dwords already in registers (software-prefetched by the caller):
+// lane t holds aligned dwords t and t+64 of the read ----
+template <int LCAP>
+__device__ __forceinline__ void gf_stage_regs(GfMapSmem<LCAP>& S, uint32_t x0, uint32_t x1, int ndw, int lane) {
+  uint8_t* codes_b = (uint8_t*)S.codes;
+  uint8_t* inv_b = (uint8_t*)S.inv;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 1 && ndw <= 64) break;
+    const int t = lane + 64 * h;
+    uint32_t code8, inv4;
+    gf_convert4(h ? x1 : x0, code8, inv4);
+    uint32_t nb = (uint32_t)__shfl_down((int)inv4, 1);
+    if (t < ndw) {
+      codes_b[t] = (uint8_t)code8;
+      if (!(lane & 1)) inv_b[t >> 1] = (uint8_t)(inv4 | (nb << 4));
+    }
+  }
+}
+
+// ---- 1. read -> 2-bit stream + invalid bits in LDS; returns the byte misalignment ----
+template <int LCAP>
+__device__ __forceinline__ uint32_t gf_stage_read(GfMapSmem<LCAP>& S, const uint8_t* p, int L, int lane) {
+  uint8_t* codes_b = (uint8_t*)S.codes;
+  uint8_t* inv_b = (uint8_t*)S.inv;
+  const uintptr_t addr = (uintptr_t)p;
+  const uint32_t sh = (uint32_t)(addr & 3u);
+  const uint32_t* pw = (const uint32_t*)(addr - sh);
+  const int ndw = (int)((sh + (uint32_t)L + 3u) >> 2);
+  for (int t0 = 0; t0 < ndw; t0 += 64) {
+    int t = t0 + lane;
+    uint32_t x = (t < ndw) ? pw[t] : 0u;
+    uint32_t code8, inv4;
+    gf_convert4(x, code8, inv4);
+    uint32_t nb = (uint32_t)__shfl_down((int)inv4, 1);
+    if (t < ndw) {
+      codes_b[t] = (uint8_t)code8;
+      if (!(lane & 1)) inv_b[t >> 1] = (uint8_t)(inv4 | (nb << 4));
+    }
+  }
+  return sh;
+}
+
+// append up to 5 votes per lane to the LDS list (ballot + mbcnt prefix sums)
+template <int LCAP>
+__device__ __forceinline__ int gf_append_votes(GfMapSmem<LCAP>& S, int nvotes, int nv, const uint32_t v[5]) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const bool has = k < nv;
+    const uint64_t m = __ballot(has);
+    if (m == 0) break;
+    if (has) S.u.votes[nvotes + gf_lanes_below(m)] = v[k];
+    nvotes += __popcll(m);
+  }
+  return nvotes;
+}
+
+// ---- 2A. first pass, producer A: probe every stride-2 window ----
+template <int LCAP>
+__device__ __forceinline__ int gf_first_pass_probe_all(const GfTable& T, GfMapSmem<LCAP>& S, int L, uint32_t sh,
+                                                       int lane) {
+  const int nwin = ((L - GF_KMER) >> 1) + 1;
+  int nvotes = 0;
+  for (int w0 = 0; w0 < nwin; w0 += 64) {
+    const int w = w0 + lane;
+    const bool act = w < nwin;
+    const uint32_t i = act ? 2u * (uint32_t)w : 0u;
+    const uint32_t g = sh + i;
+    const uint32_t key = gf_window(S.codes[g >> 4], S.codes[(g >> 4) + 1], g);
+    const uint32_t bad = gf_flags16(S.inv[g >> 5], S.inv[(g >> 5) + 1], g);
+    uint32_t val = 0;
+    if (act && !bad) val = gf_lookup(T, key);
+    uint32_t v[5];
+    const int nv = gf_sites(T, val, i, v);
+    nvotes = gf_append_votes(S, nvotes, nv, v);
+  }
+  return nvotes;
+}
+
+// ---- 2B. first pass, producer B: seed + verify (reads up to 256 bases = 2 windows per lane) ----
+// Returns the number of votes in the LDS list, or -1 when the read provably fails the gate.
+#define GF_ST_NONE 0u      /* window absent or invalid: never votes */
+#define GF_ST_UNKNOWN 1u   /* not probed yet */
+#define GF_ST_PROBED 2u    /* table result in val */
+#define GF_ST_VERIFIED 3u  /* exactly one vote, for the diagonal in val */
+
+template <int LCAP>
+__device__ __forceinline__ int gf_first_pass_seed_verify(const GfTable& T, GfMapSmem<LCAP>& S, int L,
+                                                         uint32_t sh, int lane) {
+  static_assert(LCAP <= 256 + 14, "two stride-2 windows per lane");
+  const int nwin = ((L - GF_KMER) >> 1) + 1;  // <= 128
+  uint32_t key[2], val[2], st[2], wi[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int w = lane + 64 * h;
+    const bool act = w < nwin;
+    wi[h] = act ? 2u * (uint32_t)w : 0u;
+    const uint32_t g = sh + wi[h];
+    key[h] = gf_window(S.codes[g >> 4], S.codes[(g >> 4) + 1], g);
+    const uint32_t bad = gf_flags16(S.inv[g >> 5], S.inv[(g >> 5) + 1], g);
+    st[h] = (act && !bad) ? GF_ST_UNKNOWN : GF_ST_NONE;
+    val[h] = 0;
+  }
+
+  // seeds: windows 0, 16, 32, 48 (all inside the first probing phase)
+  const bool seed = (lane & 15) == 0 && st[0] == GF_ST_UNKNOWN;
+  if (seed) {
+    val[0] = gf_lookup(T, key[0]);
+    st[0] = GF_ST_PROBED;
+  }
+  int v1 = 0, v2 = 0;  // best two candidate counts (upper bounds of their final counts minus U)
+  {
+    const bool uniq = seed && (val[0] >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE;
+    uint32_t mylin = val[0] & GF_LIN_MASK;
+    uint32_t myK = uniq ? mylin - wi[0] : GF_NONE_LIN;
+    uint64_t todo = __ballot(uniq);
+    while (todo != 0) {
+      const int leader = __builtin_ctzll(todo);
+      const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)myK, leader);
+      const uint32_t lin_seed = (uint32_t)__builtin_amdgcn_readlane((int)mylin, leader);
+      const uint64_t same = __ballot(myK == K);
+      todo &= ~same;
+      int cnt = __popcll(same);  // seed windows that already voted for K
+      // the candidate diagonal in gene coordinates
+      const int c = gf_contig_of(T, K);
+      const uint32_t base = T.lin_base[c];
+      const int32_t d = (int32_t)(K - base);
+      const bool fwd = (int32_t)(lin_seed - base) >= 0;  // position of the seed's site
+      const int32_t glen = (int32_t)T.gene_len[c];
+      const uint32_t goff = T.gene_off[c];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bool ver = false;
+        if (st[h] == GF_ST_UNKNOWN) {
+          // forward: window i sits on gene window f = d + i (indexed for 0 <= f <= len-17)
+          // reverse: f = -d - i - 15 (indexed for 1 <= f <= len-16), read = revcomp(gene)
+          const int32_t f = fwd ? d + (int32_t)wi[h] : -d - (int32_t)wi[h] - 15;
+          const bool inr = fwd ? (f >= 0 && f + GF_KMER < glen) : (f >= 1 && f + GF_KMER <= glen);
+          if (inr) {
+            const uint32_t G = goff + (uint32_t)f;
+            const uint32_t gk = gf_window(T.g2[G >> 4], T.g2[(G >> 4) + 1], G);
+            const uint32_t ub = ((fwd ? T.uf : T.ur)[G >> 5] >> (G & 31u)) & 1u;
+            ver = ub && (fwd ? gk : gf_revcomp_key(gk)) == key[h];
+          }
+        }
+        if (ver) {
+          st[h] = GF_ST_VERIFIED;
+          val[h] = K;
+        }
+        cnt += __popcll(__ballot(ver));
+      }
+      if (cnt > v1) { v2 = v1; v1 = cnt; } else if (cnt > v2) { v2 = cnt; }
+    }
+  }
+
+  // bound check: every other diagonal gets at most one vote per window that can still vote
+  const bool can0 = st[0] == GF_ST_UNKNOWN || (st[0] == GF_ST_PROBED && (val[0] >> GF_TYPE_SHIFT) == GF_TYPE_DUPES);
+  const bool can1 = st[1] == GF_ST_UNKNOWN;
+  const int open_votes = __popcll(__ballot(can0)) + __popcll(__ballot(can1));
+  if (v1 + open_votes < GF_MAJOR_KEYS / 2 || v2 + open_votes < GF_MINOR_KEYS / 2) return -1;
+
+  // probe what is still unknown: everything but the last 19 windows first
+  const int tail0 = nwin - (GF_MAJOR_KEYS / 2 - 1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (st[h] == GF_ST_UNKNOWN && lane + 64 * h < tail0) {
+      val[h] = gf_lookup(T, key[h]);
+      st[h] = GF_ST_PROBED;
+    }
+  }
+  {
+    int voted = 0, unknown = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t ty = val[h] >> GF_TYPE_SHIFT;
+      const bool has = st[h] == GF_ST_VERIFIED ||
+                       (st[h] == GF_ST_PROBED && (ty == GF_TYPE_UNIQUE || ty == GF_TYPE_DUPES));
+      voted += __popcll(__ballot(has));
+      unknown += __popcll(__ballot(st[h] == GF_ST_UNKNOWN));
+    }
+    // count1 <= number of windows that vote at all
+    if (voted + unknown < GF_MAJOR_KEYS / 2) return -1;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (st[h] == GF_ST_UNKNOWN) {
+      val[h] = gf_lookup(T, key[h]);
+      st[h] = GF_ST_PROBED;
+    }
+  }
+
+  // vote list, identical in content to producer A's
+  int nvotes = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint32_t v[5];
+    int nv = 0;
+    if (st[h] == GF_ST_VERIFIED) {
+      v[0] = val[h];
+      v[1] = v[2] = v[3] = v[4] = 0;
+      nv = 1;
+    } else if (st[h] == GF_ST_PROBED) {
+      nv = gf_sites(T, val[h], wi[h], v);
+    }
+    nvotes = gf_append_votes(S, nvotes, nv, v);
+  }
+  return nvotes;
+}
+
+// ---- 3..5: peel, gate, second pass, segment_mask, output ----
+template <int LCAP>
+__device__ __forceinline__ void gf_finish_read(const GfTable& T, GfMapSmem<LCAP>& S, int L, uint32_t sh,
+                                               int nvotes, int lane, int64_t r, uint8_t* __restrict__ counts,
+                                               gf_seqmatch* __restrict__ matches) {
+  // count1 >= 20 and count2 >= 10 on two different diagonals need >= 30 votes
+  if (nvotes < (GF_MAJOR_KEYS + GF_MINOR_KEYS) / 2) {
+    if (lane == 0) counts[r] = 0;
+    return;
+  }
+  gf_wave_lds_sync();
+
+  // peel: count equal diagonals, keep the best two with >= 10 votes
+  int64_t gp1 = 0, gp2 = 0;
+  int cnt1 = 0, cnt2 = 0;
+  {
+    const int nchunks = (nvotes + 63) >> 6;
+    int remaining = nvotes;
+    for (int k = 0; k < nchunks && remaining >= GF_MINOR_KEYS / 2; ++k) {
+      const int idx = (k << 6) + lane;
+      uint32_t mine = (idx < nvotes) ? S.u.votes[idx] : GF_NONE_LIN;
+      uint64_t alive = __ballot(mine != GF_NONE_LIN);
+      while (alive != 0 && remaining >= GF_MINOR_KEYS / 2) {
+        const int leader = __builtin_ctzll(alive);
+        const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)mine, leader);
+        const bool eq0 = mine == K;
+        int c = __popcll(__ballot(eq0));
+        if (eq0) mine = GF_NONE_LIN;
+        for (int kk = k + 1; kk < nchunks; ++kk) {  // later chunks: retired in place
+          const int j = (kk << 6) + lane;
+          const bool eq = (j < nvotes) && (S.u.votes[j] == K);
+          c += __popcll(__ballot(eq));
+          if (eq) S.u.votes[j] = GF_NONE_LIN;
+        }
+        remaining -= c;
+        alive = __ballot(mine != GF_NONE_LIN);
+        if (c >= GF_MINOR_KEYS / 2) {
+          const int ctg = gf_contig_of(T, K);
+          const int32_t d = (int32_t)(K - T.lin_base[ctg]);
+          const int64_t key64 = (int64_t)(((uint64_t)(uint32_t)ctg << 32) | (uint64_t)(uint32_t)d);
+          if (key64 != 0) {  // indexer.rs:337,342: key 0 never ranks
+            if (c > cnt1 || (c == cnt1 && key64 < gp1)) {
+              gp2 = gp1; cnt2 = cnt1; gp1 = key64; cnt1 = c;
+            } else if (c > cnt2 || (c == cnt2 && key64 < gp2)) {
+              gp2 = key64; cnt2 = c;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (cnt1 * 2 < GF_MAJOR_KEYS || cnt2 * 2 < GF_MINOR_KEYS) {
+    if (lane == 0) counts[r] = 0;
+    return;
+  }
+
+  // second pass: classify every window (stride 1)
+  uint32_t t1a = gf_lin_of_key(T, gp1 - 1), t1b = gf_lin_of_key(T, gp1), t1c = gf_lin_of_key(T, gp1 + 1);
+  uint32_t t2a = gf_lin_of_key(T, gp2 - 1), t2b = gf_lin_of_key(T, gp2), t2c = gf_lin_of_key(T, gp2 + 1);
+  const uint32_t lin0 = gf_lin_of_key(T, 0);
+  gf_wave_lds_sync();  // votes are dead; wcls/mask reuse their LDS
+  const int nwin2 = L - GF_KMER + 1;
+  for (int w0 = 0; w0 < nwin2; w0 += 64) {
+    const int w = w0 + lane;
+    const bool act = w < nwin2;
+    const uint32_t i = act ? (uint32_t)w : 0u;
+    const uint32_t g = sh + i;
+    const uint32_t key = gf_window(S.codes[g >> 4], S.codes[(g >> 4) + 1], g);
+    const uint32_t bad = gf_flags16(S.inv[g >> 5], S.inv[(g >> 5) + 1], g);
+    uint32_t val = 0;
+    if (act && !bad) val = gf_lookup(T, key);
+    uint32_t v[5];
+    const int nv = gf_sites(T, val, i, v);
+    uint32_t cls = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      if (k < nv) {
+        const uint32_t x = v[k];
+        uint32_t f = 0;
+        if (x == t1a || x == t1b || x == t1c) f = 3;       // |gplong - gp1| <= 1
+        else if (x == t2a || x == t2b || x == t2c) f = 2;  // |gplong - gp2| <= 1
+        else if (x == lin0) f = 1;                         // gplong == 0
+        cls = f > cls ? f : cls;
+      }
+    }
+    if (act) S.u.p2.wcls[w] = (uint8_t)cls;
+  }
+  gf_wave_lds_sync();
+
+  // mask[j] = max class of the windows covering base j (make_mask, :716-732)
+  int mismatches = 0;
+  for (int j0 = 0; j0 < L; j0 += 64) {
+    const int j = j0 + lane;
+    uint32_t m = 0;
+    if (j < L) {
+      const int lo = j - (GF_KMER - 1) > 0 ? j - (GF_KMER - 1) : 0;
+      const int hi = j < L - GF_KMER ? j : L - GF_KMER;
+      for (int w = lo; w <= hi; ++w) {
+        uint32_t c = S.u.p2.wcls[w];
+        m = c > m ? c : m;
+      }
+      S.u.p2.mask[j] = (uint8_t)m;
+    }
+    mismatches += __popcll(__ballot(j < L && m <= 1));
+  }
+  if (mismatches > GF_MISMATCH_THRESHOLD) {
+    if (lane == 0) counts[r] = 0;
+    return;
+  }
+  gf_wave_lds_sync();
+
+  // segment_mask: longest run per target, first start wins ties
+  int nout = 0;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int target = t == 0 ? 3 : 2;
+    uint32_t best = 0;  // (len << 16) | (0xFFFF - start)
+    for (int s = lane; s < L - 1; s += 64) {
+      if (S.u.p2.mask[s] != target) continue;
+      const int e = gf_run_end(S.u.p2.mask, L, s, target);
+      const uint32_t cand = ((uint32_t)(e - s) << 16) | (uint32_t)(0xFFFF - s);
+      best = cand > best ? cand : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)best, o);
+      best = other > best ? other : best;
+    }
+    const int blen = (int)(best >> 16);
+    if (blen > GF_THRESHOLD_LEN) {
+      if (lane == 0) {
+        const int s = 0xFFFF - (int)(best & 0xFFFFu);
+        const int64_t gp = t == 0 ? gp1 : gp2;
+        gf_seqmatch out;
+        out.seq_start = s;
+        out.seq_end = s + blen;
+        out.position = (int32_t)(uint32_t)(gp & 0xFFFFFFFFll);  // i64_to_gp, :709-714
+        out.contig = (int16_t)(gp >> 32);
+        out.pad = 0;
+        matches[2 * r + nout] = out;
+      }
+      nout += 1;
+    }
+  }
+  if (lane == 0) counts[r] = (uint8_t)nout;
+}
+
+// PRODUCER: 0 = probe all windows, 1 = seed + verify (LCAP <= 256 only)
+template <int LCAP, int WAVES, int PRODUCER>
 __global__ __launch_bounds__(WAVES * 64) void gf_k_map_reads(GfTable T, const uint8_t* __restrict__ bases,
                                                              const int64_t* __restrict__ offsets,
-                                                             int64_t n, uint8_t* __restrict__ counts,
+                                                             int64_t n, int lmin, int mark_too_long,
+                                                             uint8_t* __restrict__ counts,
                                                              gf_seqmatch* __restrict__ matches) {
+  // handles the reads with lmin < length <= LCAP; shorter ones belong to another
+  // launch of the same batch, longer ones too unless this is the top length class
   __shared__ GfMapSmem<LCAP> smem[WAVES];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   GfMapSmem<LCAP>& S = smem[wib];
-  uint8_t* codes_b = (uint8_t*)S.codes;
-  uint8_t* inv_b = (uint8_t*)S.inv;
   const int64_t stride = (int64_t)gridDim.x * WAVES;
 
   for (int64_t r = (int64_t)blockIdx.x * WAVES + wib; r < n; r += stride) {
     const int64_t off0 = offsets[r];
     const int64_t len64 = offsets[r + 1] - off0;
     if (len64 > LCAP) {
-      if (lane == 0) counts[r] = GF_COUNT_TOO_LONG;
+      if (mark_too_long && lane == 0) counts[r] = GF_COUNT_TOO_LONG;
       continue;
     }
+    if (len64 <= lmin) continue;
     const int L = (int)len64;
     if (L < GF_KMER) {  // no window (also covers malformed negative lengths)
       if (lane == 0) counts[r] = 0;
       continue;
     }
-
-    // ---- 1. read -> 2-bit stream + invalid bits in LDS ----
-    const uintptr_t addr = (uintptr_t)(bases + off0);
-    const uint32_t sh = (uint32_t)(addr & 3u);
-    const uint32_t* pw = (const uint32_t*)(addr - sh);
-    const int ndw = (int)((sh + (uint32_t)L + 3u) >> 2);
     gf_wave_lds_sync();  // previous read's LDS traffic is finished
-    for (int t0 = 0; t0 < ndw; t0 += 64) {
-      int t = t0 + lane;
-      uint32_t x = (t < ndw) ? pw[t] : 0u;
-      uint32_t code8, inv4;
-      gf_convert4(x, code8, inv4);
-      uint32_t nb = (uint32_t)__shfl_down((int)inv4, 1);
-      if (t < ndw) {
-        codes_b[t] = (uint8_t)code8;
-        if (!(lane & 1)) inv_b[t >> 1] = (uint8_t)(inv4 | (nb << 4));
-      }
-    }
+    const uint32_t sh = gf_stage_read<LCAP>(S, bases + off0, L, lane);
     gf_wave_lds_sync();
+    int nvotes;
+    if constexpr (PRODUCER == 1) nvotes = gf_first_pass_seed_verify<LCAP>(T, S, L, sh, lane);
+    else nvotes = gf_first_pass_probe_all<LCAP>(T, S, L, sh, lane);
+    gf_finish_read<LCAP>(T, S, L, sh, nvotes, lane, r, counts, matches);
+  }
+}
 
-    // ---- 2. first pass: stride-2 windows vote ----
-    const int nwin = ((L - GF_KMER) >> 1) + 1;
-    int nvotes = 0;
-    for (int w0 = 0; w0 < nwin; w0 += 64) {
-      const int w = w0 + lane;
-      const bool act = w < nwin;
-      const uint32_t i = act ? 2u * (uint32_t)w : 0u;
-      const uint32_t g = sh + i;
-      const uint32_t key = gf_window(S.codes[g >> 4], S.codes[(g >> 4) + 1], g);
-      const uint32_t bad = gf_flags16(S.inv[g >> 5], S.inv[(g >> 5) + 1], g);
-      uint32_t val = 0;
-      if (act && !bad) val = gf_lookup(T, key);
-      uint32_t v[5];
-      const int nv = gf_sites(T, val, i, v);
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const bool has = k < nv;
-        const uint64_t m = __ballot(has);
-        if (m == 0) break;
-        if (has) S.u.votes[nvotes + gf_lanes_below(m)] = v[k];
-        nvotes += __popcll(m);
-      }
+// The <= 256-base class with a two-deep software pipeline over the reads of a wave:
+// while read k is processed, the bases of read k+1 and the offsets of read k+2 are
+// already in flight, so the per-read dependent chain shrinks from
+// offsets -> bases -> seeds -> verify/probe to seeds -> verify/probe.
+template <int WAVES, int PRODUCER>
+__global__ __launch_bounds__(WAVES * 64, 8) void gf_k_map_reads_short(GfTable T, const uint8_t* __restrict__ bases,
+                                                                      const int64_t* __restrict__ offsets,
+                                                                      int64_t n, int mark_too_long,
+                                                                      uint8_t* __restrict__ counts,
+                                                                      gf_seqmatch* __restrict__ matches) {
+  constexpr int LCAP = 256;
+  __shared__ GfMapSmem<LCAP> smem[WAVES];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  GfMapSmem<LCAP>& S = smem[wib];
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  const int64_t r0 = (int64_t)blockIdx.x * WAVES + wib;
+  if (r0 >= n) return;
+
+  // pipeline registers: [cur] bases loaded, [nxt] offsets loaded
+  int64_t cur_off = offsets[r0], cur_end = offsets[r0 + 1];
+  int64_t nxt_off = 0, nxt_end = 0;
+  if (r0 + stride < n) {
+    nxt_off = offsets[r0 + stride];
+    nxt_end = offsets[r0 + stride + 1];
+  }
+  auto load_bases = [&](int64_t off, int64_t end, uint32_t& x0, uint32_t& x1) {
+    const int64_t len = end - off;
+    x0 = 0;
+    x1 = 0;
+    if (len >= GF_KMER && len <= LCAP) {
+      const uintptr_t addr = (uintptr_t)(bases + off);
+      const uint32_t sh = (uint32_t)(addr & 3u);
+      const uint32_t* pw = (const uint32_t*)(addr - sh);
+      const int ndw = (int)((sh + (uint32_t)len + 3u) >> 2);
+      if (lane < ndw) x0 = pw[lane];
+      if (lane + 64 < ndw) x1 = pw[lane + 64];
+    }
+  };
+  uint32_t cur_x0, cur_x1;
+  load_bases(cur_off, cur_end, cur_x0, cur_x1);
+
+  for (int64_t r = r0; r < n; r += stride) {
+    // issue the next read's bases and the offsets of the one after it
+    uint32_t nxt_x0 = 0, nxt_x1 = 0;
+    int64_t nn_off = 0, nn_end = 0;
+    const bool have_next = r + stride < n;
+    if (have_next) load_bases(nxt_off, nxt_end, nxt_x0, nxt_x1);
+    if (r + 2 * stride < n) {
+      nn_off = offsets[r + 2 * stride];
+      nn_end = offsets[r + 2 * stride + 1];
     }
 
-    // count1 >= 20 and count2 >= 10 on two different diagonals need >= 30 votes
-    if (nvotes < (GF_MAJOR_KEYS + GF_MINOR_KEYS) / 2) {
+    const int64_t len64 = cur_end - cur_off;
+    if (len64 > LCAP) {
+      if (mark_too_long && lane == 0) counts[r] = GF_COUNT_TOO_LONG;
+    } else if (len64 < GF_KMER) {
       if (lane == 0) counts[r] = 0;
-      continue;
+    } else {
+      const int L = (int)len64;
+      const uint32_t sh = (uint32_t)((uintptr_t)(bases + cur_off) & 3u);
+      const int ndw = (int)((sh + (uint32_t)L + 3u) >> 2);
+      gf_wave_lds_sync();  // previous read's LDS traffic is finished
+      gf_stage_regs<LCAP>(S, cur_x0, cur_x1, ndw, lane);
+      gf_wave_lds_sync();
+      int nvotes;
+      if constexpr (PRODUCER == 1) nvotes = gf_first_pass_seed_verify<LCAP>(T, S, L, sh, lane);
+      else nvotes = gf_first_pass_probe_all<LCAP>(T, S, L, sh, lane);
+      gf_finish_read<LCAP>(T, S, L, sh, nvotes, lane, r, counts, matches);
     }
-    gf_wave_lds_sync();
-
-    // ---- 3. peel: count equal diagonals, keep the best two with >= 10 votes ----
-    int64_t gp1 = 0, gp2 = 0;
-    int cnt1 = 0, cnt2 = 0;
-    {
-      const int nchunks = (nvotes + 63) >> 6;
-      int remaining = nvotes;
-      // dead[k] for k < 64 chunks: NVOTES/64 <= 160 for LCAP 4096 -> keep flags in LDS-free
-      // form: a vote is dead once overwritten with GF_NONE_LIN in the list itself.
-      for (int k = 0; k < nchunks && remaining >= GF_MINOR_KEYS / 2; ++k) {
-        const int idx = (k << 6) + lane;
-        uint32_t mine = (idx < nvotes) ? S.u.votes[idx] : GF_NONE_LIN;
-        uint64_t alive = __ballot(mine != GF_NONE_LIN);
-        while (alive != 0 && remaining >= GF_MINOR_KEYS / 2) {
-          const int leader = __builtin_ctzll(alive);
-          const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)mine, leader);
-          // votes equal to K in this chunk ...
-          const bool eq0 = mine == K;
-          int c = __popcll(__ballot(eq0));
-          if (eq0) mine = GF_NONE_LIN;
-          // ... and in the later chunks (marked dead in place)
-          for (int kk = k + 1; kk < nchunks; ++kk) {
-            const int j = (kk << 6) + lane;
-            const bool eq = (j < nvotes) && (S.u.votes[j] == K);
-            c += __popcll(__ballot(eq));
-            if (eq) S.u.votes[j] = GF_NONE_LIN;
-          }
-          remaining -= c;
-          alive = __ballot(mine != GF_NONE_LIN);
-          if (c >= GF_MINOR_KEYS / 2) {
-            const int ctg = gf_contig_of(T, K);
-            const int32_t d = (int32_t)(K - T.lin_base[ctg]);
-            const int64_t key64 = (int64_t)(((uint64_t)(uint32_t)ctg << 32) | (uint64_t)(uint32_t)d);
-            if (key64 != 0) {  // indexer.rs:337,342: key 0 never ranks
-              if (c > cnt1 || (c == cnt1 && key64 < gp1)) {
-                gp2 = gp1; cnt2 = cnt1; gp1 = key64; cnt1 = c;
-              } else if (c > cnt2 || (c == cnt2 && key64 < gp2)) {
-                gp2 = key64; cnt2 = c;
-              }
-            }
-          }
-        }
-      }
-    }
-    if (cnt1 * 2 < GF_MAJOR_KEYS || cnt2 * 2 < GF_MINOR_KEYS) {
-      if (lane == 0) counts[r] = 0;
-      continue;
-    }
-
-    // ---- 4. second pass: classify every window (stride 1) ----
-    uint32_t t1a = gf_lin_of_key(T, gp1 - 1), t1b = gf_lin_of_key(T, gp1), t1c = gf_lin_of_key(T, gp1 + 1);
-    uint32_t t2a = gf_lin_of_key(T, gp2 - 1), t2b = gf_lin_of_key(T, gp2), t2c = gf_lin_of_key(T, gp2 + 1);
-    const uint32_t lin0 = gf_lin_of_key(T, 0);
-    gf_wave_lds_sync();  // votes are dead; wcls/mask reuse their LDS
-    const int nwin2 = L - GF_KMER + 1;
-    for (int w0 = 0; w0 < nwin2; w0 += 64) {
-      const int w = w0 + lane;
-      const bool act = w < nwin2;
-      const uint32_t i = act ? (uint32_t)w : 0u;
-      const uint32_t g = sh + i;
-      const uint32_t key = gf_window(S.codes[g >> 4], S.codes[(g >> 4) + 1], g);
-      const uint32_t bad = gf_flags16(S.inv[g >> 5], S.inv[(g >> 5) + 1], g);
-      uint32_t val = 0;
-      if (act && !bad) val = gf_lookup(T, key);
-      uint32_t v[5];
-      const int nv = gf_sites(T, val, i, v);
-      uint32_t cls = 0;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        if (k < nv) {
-          const uint32_t x = v[k];
-          uint32_t f = 0;
-          if (x == t1a || x == t1b || x == t1c) f = 3;       // |gplong - gp1| <= 1
-          else if (x == t2a || x == t2b || x == t2c) f = 2;  // |gplong - gp2| <= 1
-          else if (x == lin0) f = 1;                         // gplong == 0
-          cls = f > cls ? f : cls;
-        }
-      }
-      if (act) S.u.p2.wcls[w] = (uint8_t)cls;
-    }
-    gf_wave_lds_sync();
-
-    // mask[j] = max class of the windows covering base j (make_mask, :716-732)
-    int mismatches = 0;
-    for (int j0 = 0; j0 < L; j0 += 64) {
-      const int j = j0 + lane;
-      uint32_t m = 0;
-      if (j < L) {
-        const int lo = j - (GF_KMER - 1) > 0 ? j - (GF_KMER - 1) : 0;
-        const int hi = j < L - GF_KMER ? j : L - GF_KMER;
-        for (int w = lo; w <= hi; ++w) {
-          uint32_t c = S.u.p2.wcls[w];
-          m = c > m ? c : m;
-        }
-        S.u.p2.mask[j] = (uint8_t)m;
-      }
-      mismatches += __popcll(__ballot(j < L && m <= 1));
-    }
-    if (mismatches > GF_MISMATCH_THRESHOLD) {
-      if (lane == 0) counts[r] = 0;
-      continue;
-    }
-    gf_wave_lds_sync();
-
-    // ---- 5. segment_mask: longest run per target, first start wins ties ----
-    int nout = 0;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int target = t == 0 ? 3 : 2;
-      uint32_t best = 0;  // (len << 16) | (0xFFFF - start)
-      for (int s = lane; s < L - 1; s += 64) {
-        if (S.u.p2.mask[s] != target) continue;
-        const int e = gf_run_end(S.u.p2.mask, L, s, target);
-        const uint32_t cand = ((uint32_t)(e - s) << 16) | (uint32_t)(0xFFFF - s);
-        best = cand > best ? cand : best;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)best, o);
-        best = other > best ? other : best;
-      }
-      const int blen = (int)(best >> 16);
-      if (blen > GF_THRESHOLD_LEN) {
-        if (lane == 0) {
-          const int s = 0xFFFF - (int)(best & 0xFFFFu);
-          const int64_t gp = t == 0 ? gp1 : gp2;
-          gf_seqmatch out;
-          out.seq_start = s;
-          out.seq_end = s + blen;
-          out.position = (int32_t)(uint32_t)(gp & 0xFFFFFFFFll);  // i64_to_gp, :709-714
-          out.contig = (int16_t)(gp >> 32);
-          out.pad = 0;
-          matches[2 * r + nout] = out;
-        }
-        nout += 1;
-      }
-    }
-    if (lane == 0) counts[r] = (uint8_t)nout;
+    cur_off = nxt_off; cur_end = nxt_end; cur_x0 = nxt_x0; cur_x1 = nxt_x1;
+    nxt_off = nn_off; nxt_end = nn_end;
   }
 }
 

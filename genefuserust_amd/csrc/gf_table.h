@@ -59,6 +59,13 @@ struct GfTable {
   const uint32_t* lin_base; // [n_genes]   lin of (contig, position 0)
   const uint32_t* lin_hi;   // [n_genes]   exclusive upper end of contig's interval
   const uint32_t* gene_len; // [n_genes]
+  // diagonal verification (gf_map_kernels.h, v2): the genes themselves, 2 bits per
+  // base in concatenated coordinates, and per window start one bit per strand that
+  // says "this window's key occurs exactly once in the index, here"
+  const uint32_t* gene_off; // [n_genes + 1] start of each gene in concatenated coordinates
+  const uint32_t* g2;       // 16 bases per word, base g in bits [2(g%16), 2(g%16)+1]
+  const uint32_t* uf;       // bit g: forward site of window g is the unique site of its key
+  const uint32_t* ur;       // bit g: reverse-complement site of window g is unique
   uint32_t nbuckets;
   int32_t n_genes;
 };

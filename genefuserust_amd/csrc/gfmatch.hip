@@ -84,6 +84,11 @@ struct gf_index {
   uint32_t* d_lin_base = nullptr;
   uint32_t* d_lin_hi = nullptr;
   uint32_t* d_gene_len = nullptr;
+  uint32_t* d_gene_off = nullptr;
+  uint32_t* d_g2 = nullptr;
+  uint32_t* d_uf = nullptr;
+  uint32_t* d_ur = nullptr;
+  int map_variant = 0;  // 0 = auto (seed+verify for reads <= 256), 1 = probe every window
   std::vector<std::string> fusion_seq;  // Indexer.m_fusion_seq (indexer.rs:77)
   gf_index_info info{};
   // profiling
@@ -99,6 +104,10 @@ struct gf_index {
     if (d_lin_base) (void)hipFree(d_lin_base);
     if (d_lin_hi) (void)hipFree(d_lin_hi);
     if (d_gene_len) (void)hipFree(d_gene_len);
+    if (d_gene_off) (void)hipFree(d_gene_off);
+    if (d_g2) (void)hipFree(d_g2);
+    if (d_uf) (void)hipFree(d_uf);
+    if (d_ur) (void)hipFree(d_ur);
     if (have_events) {
       (void)hipEventDestroy(ev0);
       (void)hipEventDestroy(ev1);
@@ -171,11 +180,19 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   const uint64_t nslots = (uint64_t)nbuckets * GF_SLOTS_PER_BUCKET;
 
   DevBuf<uint8_t> d_cat;
-  DevBuf<uint32_t> d_goff;
   DevBuf<unsigned long long> d_stats;
   GF_HIP(d_cat.alloc(cat_bytes));
-  GF_HIP(d_goff.alloc((size_t)n_genes + 1));
+  GF_HIP(hipMalloc((void**)&ix->d_gene_off, ((size_t)n_genes + 1) * sizeof(uint32_t)));
   GF_HIP(d_stats.alloc(8));
+  // packed genes + uniqueness bits for the diagonal verification of the mapping kernel
+  const size_t g2_words = (size_t)ntiles * (GF_TILE_BASES / 16) + 8;
+  const size_t ub_words = (size_t)ntiles * (GF_TILE_BASES / 32) + 8;
+  GF_HIP(hipMalloc((void**)&ix->d_g2, g2_words * sizeof(uint32_t)));
+  GF_HIP(hipMalloc((void**)&ix->d_uf, ub_words * sizeof(uint32_t)));
+  GF_HIP(hipMalloc((void**)&ix->d_ur, ub_words * sizeof(uint32_t)));
+  GF_HIP(hipMemset(ix->d_g2, 0, g2_words * sizeof(uint32_t)));
+  GF_HIP(hipMemset(ix->d_uf, 0, ub_words * sizeof(uint32_t)));
+  GF_HIP(hipMemset(ix->d_ur, 0, ub_words * sizeof(uint32_t)));
   GF_HIP(hipMalloc((void**)&ix->d_slots, nslots * sizeof(uint64_t)));
   GF_HIP(hipMalloc((void**)&ix->d_lin_base, lin_base.size() * sizeof(uint32_t)));
   GF_HIP(hipMalloc((void**)&ix->d_lin_hi, lin_hi.size() * sizeof(uint32_t)));
@@ -183,14 +200,14 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   GF_HIP(hipMemset(ix->d_slots, 0, nslots * sizeof(uint64_t)));
   GF_HIP(hipMemset(d_stats.p, 0, 8 * sizeof(unsigned long long)));
   GF_HIP(hipMemcpy(d_cat.p, cat.data(), cat_bytes, hipMemcpyHostToDevice));
-  GF_HIP(hipMemcpy(d_goff.p, gene_off.data(), gene_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(ix->d_gene_off, gene_off.data(), gene_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   GF_HIP(hipMemcpy(ix->d_lin_base, lin_base.data(), lin_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   GF_HIP(hipMemcpy(ix->d_lin_hi, lin_hi.data(), lin_hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   GF_HIP(hipMemcpy(ix->d_gene_len, glen.data(), glen.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 
   GfGenes G;
   G.cat = d_cat.p;
-  G.gene_off = d_goff.p;
+  G.gene_off = ix->d_gene_off;
   G.lin_base = ix->d_lin_base;
   G.total = (uint32_t)total;
   G.n_genes = n_genes;
@@ -219,6 +236,11 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   }
   hipLaunchKernelGGL(gf_k_sort_dupes, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_dupes);
   GF_HIP(hipGetLastError());
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(gf_k_index_ubits, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G, ix->d_slots, nbuckets,
+                       ix->d_g2, ix->d_uf, ix->d_ur);
+    GF_HIP(hipGetLastError());
+  }
   GF_HIP(hipDeviceSynchronize());
 
   ix->table.slots = ix->d_slots;
@@ -226,6 +248,10 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   ix->table.lin_base = ix->d_lin_base;
   ix->table.lin_hi = ix->d_lin_hi;
   ix->table.gene_len = ix->d_gene_len;
+  ix->table.gene_off = ix->d_gene_off;
+  ix->table.g2 = ix->d_g2;
+  ix->table.uf = ix->d_uf;
+  ix->table.ur = ix->d_ur;
   ix->table.nbuckets = nbuckets;
   ix->table.n_genes = n_genes;
 
@@ -239,7 +265,8 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   I.n_high_keys = (int64_t)stats[4];
   I.n_dupe_sites = (int64_t)stats[5];
   I.n_buckets = nbuckets;
-  I.table_bytes = (int64_t)(nslots * sizeof(uint64_t) + std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t));
+  I.table_bytes = (int64_t)(nslots * sizeof(uint64_t) + std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t) +
+                            (g2_words + 2 * ub_words) * sizeof(uint32_t));
   I.device = dev;
   *out_index = ix.release();
   return GF_OK;
@@ -313,21 +340,31 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
   uint8_t* counts = (uint8_t*)d_counts;
   gf_seqmatch* matches = (gf_seqmatch*)d_matches;
   // persistent grid: enough waves to fill every CU, reads interleaved across waves
-  if (max_read_len <= 256) {
+  // One launch per read-length class present in the batch (<=256, <=1024, <=4096);
+  // each launch skips the reads of the other classes, so short reads always get the
+  // small-LDS kernel with the seed+verify first pass.
+  const int top = max_read_len <= 256 ? 0 : (max_read_len <= 1024 ? 1 : 2);
+  {
     constexpr int W = 4;
-    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 8 * 2);
-    hipLaunchKernelGGL((gf_k_map_reads<256, W>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets, n,
-                       counts, matches);
-  } else if (max_read_len <= 1024) {
+    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 8);
+    if (idx->map_variant == 1)
+      hipLaunchKernelGGL((gf_k_map_reads_short<W, 0>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
+                         n, top == 0 ? 1 : 0, counts, matches);
+    else
+      hipLaunchKernelGGL((gf_k_map_reads_short<W, 1>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
+                         n, top == 0 ? 1 : 0, counts, matches);
+  }
+  if (top >= 1) {
     constexpr int W = 4;
     int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 4 * 2);
-    hipLaunchKernelGGL((gf_k_map_reads<1024, W>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
-                       n, counts, matches);
-  } else {
+    hipLaunchKernelGGL((gf_k_map_reads<1024, W, 0>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
+                       n, 256, top == 1 ? 1 : 0, counts, matches);
+  }
+  if (top >= 2) {
     constexpr int W = 2;
     int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 2 * 2);
-    hipLaunchKernelGGL((gf_k_map_reads<4096, W>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
-                       n, counts, matches);
+    hipLaunchKernelGGL((gf_k_map_reads<4096, W, 0>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
+                       n, 1024, 1, counts, matches);
   }
   GF_HIP(hipGetLastError());
   if (prof) {
@@ -484,6 +521,12 @@ int gf_in_required_direction(const gf_seqmatch* m, int32_t n, const uint8_t* gen
   if (left->contig < right->contig) return 1;
   // the reference's same-contig test compares left with itself (:598) and is never true
   return 0;
+}
+
+int gf_set_map_variant(gf_index* idx, int32_t variant) {
+  if (!idx || variant < 0 || variant > 1) return fail(GF_ERR_ARG, "bad variant");
+  idx->map_variant = variant;
+  return GF_OK;
 }
 
 int gf_set_profiling(gf_index* idx, int32_t on) {

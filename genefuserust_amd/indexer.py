@@ -236,6 +236,10 @@ class Indexer:
     def set_profiling(self, on: bool) -> None:
         _lib.check(_lib.lib().gf_set_profiling(self._handle(), int(on)))
 
+    def set_map_variant(self, variant: int) -> None:
+        """0 = seed + verify first pass (default), 1 = probe every window."""
+        _lib.check(_lib.lib().gf_set_map_variant(self._handle(), int(variant)))
+
     def last_map_kernel_ms(self) -> float:
         return float(_lib.lib().gf_last_map_kernel_ms(self._handle()))
 

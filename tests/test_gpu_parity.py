@@ -80,9 +80,13 @@ def test_index_content_every_key(branch_index, golden):
     assert not cnt.any()
 
 
-def test_map_golden_cases(branch_index, golden):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_map_golden_cases(branch_index, golden, variant):
+    """variant 0 = seed+verify first pass (reads <= 256), 1 = probe every window."""
+    branch_index.set_map_variant(variant)
     reads = [c["read"].encode() for c in golden["cases"]]
     got = branch_index.map_reads(reads)
+    branch_index.set_map_variant(0)
     for c, g in zip(golden["cases"], got):
         flat = [(m.seq_start, m.seq_end, m.start_gp.contig, m.start_gp.position) for m in g]
         assert flat == [tuple(m) for m in c["expect"]], c["label"]
@@ -194,8 +198,9 @@ def test_with_loaded_ref_constructor(gpu_device, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("shape,scale,n_reads", [("IDX-T", 0.02, 60000), ("IDX-C", 0.004, 60000)])
-def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads):
+def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, variant):
     """Repeat-rich synthetic genes (2 % repeat family, N bases) and a junction-heavy
     read mix: every read's SeqMatch list equals the oracle's."""
     from genefuserust_amd import Indexer
@@ -203,6 +208,7 @@ def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads):
     genes = synth.make_geneset(shape, scale=scale)
     ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
     ix.make_index()
+    ix.set_map_variant(variant)
     ox = oracle.OracleIndexer(genes.seqs)
     info = ix.info()
     st = ox.stats()
