@@ -152,15 +152,13 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_sites(GfGenes G, 
   }
 }
 
-// After FILL: publish the 2-bit packed genes (g2) and the per-window uniqueness bits
-// (uf, ur) used by the mapping kernel's diagonal verification.  Same tiling as
-// gf_k_index_sites; every word of the tile is written (no atomics: one wave owns 64
-// consecutive windows = two whole words).
-__global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_ubits(GfGenes G, uint64_t* slots,
-                                                                     uint32_t nbuckets,
-                                                                     uint32_t* __restrict__ g2,
-                                                                     uint32_t* __restrict__ uf,
-                                                                     uint32_t* __restrict__ ur) {
+// After FILL: publish both strands of the genes in site-code space (gd) and the
+// per-site uniqueness bits (ub) used by the mapping kernel's diagonal verification
+// (layout: gf_table.h).  gd and ub are zero-filled by the host; bits are OR-ed in.
+__global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_strands(GfGenes G, uint64_t* slots,
+                                                                       uint32_t nbuckets,
+                                                                       uint32_t* __restrict__ gd,
+                                                                       uint32_t* __restrict__ ub) {
   __shared__ uint32_t s_codes[GF_TILE_BASES / 16 + 2];
   __shared__ uint32_t s_inv[GF_TILE_BASES / 32 + 2];
   const uint32_t t0 = blockIdx.x * GF_TILE_BASES;
@@ -172,9 +170,7 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_ubits(GfGenes G, 
     gf_convert4(q.y, c1, i1);
     gf_convert4(q.z, c2, i2);
     gf_convert4(q.w, c3, i3);
-    uint32_t w = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-    s_codes[ch] = w;
-    if (ch < GF_TILE_BASES / 16) g2[t0 / 16 + ch] = w;
+    s_codes[ch] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
     ((uint16_t*)s_inv)[ch] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
   }
   if (tid == 0) {
@@ -184,37 +180,44 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_ubits(GfGenes G, 
     ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 3] = 0xFFFF;
   }
   __syncthreads();
-  for (int l = tid; l < GF_TILE_BASES; l += GF_INDEX_THREADS) {  // uniform trip count
+  for (int l = tid; l < GF_TILE_BASES; l += GF_INDEX_THREADS) {
     const uint32_t g = t0 + (uint32_t)l;
-    bool u_f = false, u_r = false;
-    if (g < G.total && !gf_flags16(s_inv[l >> 5], s_inv[(l >> 5) + 1], (uint32_t)l)) {
-      int lo = 0, hi = G.n_genes;
-      while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (G.gene_off[mid] <= g) lo = mid; else hi = mid;
-      }
-      const uint32_t f = g - G.gene_off[lo];
-      const uint32_t len = G.gene_off[lo + 1] - G.gene_off[lo];
-      if (f + GF_KMER <= len) {
-        const uint32_t key = gf_window(s_codes[l >> 4], s_codes[(l >> 4) + 1], (uint32_t)l);
-        if (f + GF_KMER < len) {
-          const uint64_t* s = gf_find_slot(slots, nbuckets, key);
-          u_f = s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE;
-        }
-        if (f >= 1) {
-          const uint64_t* s = gf_find_slot(slots, nbuckets, gf_revcomp_key(key));
-          u_r = s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE;
-        }
+    if (g >= G.total) break;
+    int lo = 0, hi = G.n_genes;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (G.gene_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    const uint32_t f = g - G.gene_off[lo];
+    const uint32_t len = G.gene_off[lo + 1] - G.gene_off[lo];
+    const uint32_t base = G.lin_base[lo];
+    // this base on both strands (invalid bases keep code 0: their windows carry no ub bit)
+    const uint32_t code = (s_codes[l >> 4] >> (2 * (l & 15))) & 3u;
+    const bool bad = (s_inv[l >> 5] >> (l & 31)) & 1u;
+    if (!bad) {
+      const uint32_t pf = base + f;
+      if (code) atomicOr(gd + (pf >> 4), code << (2 * (pf & 15u)));
+      if (f >= 1) {
+        const uint32_t pr = base - f;  // reverse-complement base j = len-1-f at base + 1 - len + j
+        atomicOr(gd + (pr >> 4), (code ^ 2u) << (2 * (pr & 15u)));
       }
     }
-    const uint64_t mf = __ballot(u_f), mr = __ballot(u_r);
-    const int lane = tid & 63;
-    if (lane == 0) {
-      uf[g >> 5] = (uint32_t)mf;
-      ur[g >> 5] = (uint32_t)mr;
-    } else if (lane == 32) {
-      uf[g >> 5] = (uint32_t)(mf >> 32);
-      ur[g >> 5] = (uint32_t)(mr >> 32);
+    if (f + GF_KMER > len) continue;
+    if (gf_flags16(s_inv[l >> 5], s_inv[(l >> 5) + 1], (uint32_t)l)) continue;
+    const uint32_t key = gf_window(s_codes[l >> 4], s_codes[(l >> 4) + 1], (uint32_t)l);
+    if (f + GF_KMER < len) {
+      const uint64_t* s = gf_find_slot(slots, nbuckets, key);
+      if (s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) {
+        const uint32_t p = base + f;
+        atomicOr(ub + (p >> 5), 1u << (p & 31u));
+      }
+    }
+    if (f >= 1) {
+      const uint64_t* s = gf_find_slot(slots, nbuckets, gf_revcomp_key(key));
+      if (s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) {
+        const uint32_t p = base - (f + 15u);
+        atomicOr(ub + (p >> 5), 1u << (p & 31u));
+      }
     }
   }
 }

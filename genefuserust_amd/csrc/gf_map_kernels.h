@@ -28,11 +28,12 @@
 // First pass, producer B ("seed + verify", reads up to 256 bases): exact, but
 // spends far fewer L2-missing requests:
 //   * 4 seed windows are probed; every UNIQUE seed hit names a candidate diagonal;
-//   * each candidate is verified against the genes themselves: window i is
-//     *verified* when its 16 bases equal the gene's window on that diagonal and that
-//     gene window's key is flagged unique in the index (uf/ur bits) — then the table
-//     would return exactly that one site, i.e. exactly one vote for the candidate,
-//     so the probe is skipped.  One diagonal costs ~3 cache lines instead of 68;
+//   * each candidate is verified against the genes themselves, stored for both
+//     strands in site-code space (gf_table.h: gd, ub): window i is *verified* when its
+//     16 bases equal the bases of site K+i and that site is flagged as the only site
+//     of its key — then the table would return exactly that one site, i.e. exactly one
+//     vote for the candidate, so the probe is skipped.  No contig decode, no strand
+//     logic; one diagonal costs ~3 cache lines instead of 68;
 //   * bound check: a diagonal can collect at most one vote per window, so with U
 //     windows still unknown the best two counts are at most v1+U and v2+U; if
 //     v1+U < 20 or v2+U < 10 the read cannot pass the gate -> [] without probing;
@@ -262,37 +263,24 @@ __device__ __forceinline__ int gf_first_pass_seed_verify(const GfTable& T, GfMap
   int v1 = 0, v2 = 0;  // best two candidate counts (upper bounds of their final counts minus U)
   {
     const bool uniq = seed && (val[0] >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE;
-    uint32_t mylin = val[0] & GF_LIN_MASK;
-    uint32_t myK = uniq ? mylin - wi[0] : GF_NONE_LIN;
+    uint32_t myK = uniq ? (val[0] & GF_LIN_MASK) - wi[0] : GF_NONE_LIN;
     uint64_t todo = __ballot(uniq);
     while (todo != 0) {
       const int leader = __builtin_ctzll(todo);
       const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)myK, leader);
-      const uint32_t lin_seed = (uint32_t)__builtin_amdgcn_readlane((int)mylin, leader);
       const uint64_t same = __ballot(myK == K);
       todo &= ~same;
       int cnt = __popcll(same);  // seed windows that already voted for K
-      // the candidate diagonal in gene coordinates
-      const int c = gf_contig_of(T, K);
-      const uint32_t base = T.lin_base[c];
-      const int32_t d = (int32_t)(K - base);
-      const bool fwd = (int32_t)(lin_seed - base) >= 0;  // position of the seed's site
-      const int32_t glen = (int32_t)T.gene_len[c];
-      const uint32_t goff = T.gene_off[c];
+      // window i lies on candidate K iff its 16 bases equal the site K+i's bases in
+      // site-code space and that site is the unique site of its key (gf_table.h)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         bool ver = false;
         if (st[h] == GF_ST_UNKNOWN) {
-          // forward: window i sits on gene window f = d + i (indexed for 0 <= f <= len-17)
-          // reverse: f = -d - i - 15 (indexed for 1 <= f <= len-16), read = revcomp(gene)
-          const int32_t f = fwd ? d + (int32_t)wi[h] : -d - (int32_t)wi[h] - 15;
-          const bool inr = fwd ? (f >= 0 && f + GF_KMER < glen) : (f >= 1 && f + GF_KMER <= glen);
-          if (inr) {
-            const uint32_t G = goff + (uint32_t)f;
-            const uint32_t gk = gf_window(T.g2[G >> 4], T.g2[(G >> 4) + 1], G);
-            const uint32_t ub = ((fwd ? T.uf : T.ur)[G >> 5] >> (G & 31u)) & 1u;
-            ver = ub && (fwd ? gk : gf_revcomp_key(gk)) == key[h];
-          }
+          const uint32_t a = K + wi[h];
+          const uint32_t gk = gf_window(T.gd[a >> 4], T.gd[(a >> 4) + 1], a);
+          const uint32_t ubit = (T.ub[a >> 5] >> (a & 31u)) & 1u;
+          ver = ubit && gk == key[h];
         }
         if (ver) {
           st[h] = GF_ST_VERIFIED;

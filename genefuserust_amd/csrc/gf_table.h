@@ -59,13 +59,15 @@ struct GfTable {
   const uint32_t* lin_base; // [n_genes]   lin of (contig, position 0)
   const uint32_t* lin_hi;   // [n_genes]   exclusive upper end of contig's interval
   const uint32_t* gene_len; // [n_genes]
-  // diagonal verification (gf_map_kernels.h, v2): the genes themselves, 2 bits per
-  // base in concatenated coordinates, and per window start one bit per strand that
-  // says "this window's key occurs exactly once in the index, here"
-  const uint32_t* gene_off; // [n_genes + 1] start of each gene in concatenated coordinates
-  const uint32_t* g2;       // 16 bases per word, base g in bits [2(g%16), 2(g%16)+1]
-  const uint32_t* uf;       // bit g: forward site of window g is the unique site of its key
-  const uint32_t* ur;       // bit g: reverse-complement site of window g is unique
+  // diagonal verification (gf_map_kernels.h, seed+verify): both strands of every gene
+  // laid out in site-code ("lin") space, so that the 16 bases of the site with code
+  // lin sit at positions lin .. lin+15 whatever its contig and strand:
+  //   forward base f of contig c            at lin_base[c] + f
+  //   reverse-complement base j (0-based)   at lin_base[c] + 1 - len_c + j
+  // (the two meet at lin_base[c]; it is given to the forward strand — the reverse
+  // strand's last base belongs to no indexed window, indexer.rs:188.)
+  const uint32_t* gd;       // 2 bits per base, base p in bits [2(p%16), 2(p%16)+1] of word p/16
+  const uint32_t* ub;       // bit p: the site with code p exists and is the only site of its key
   uint32_t nbuckets;
   int32_t n_genes;
 };

@@ -84,10 +84,8 @@ struct gf_index {
   uint32_t* d_lin_base = nullptr;
   uint32_t* d_lin_hi = nullptr;
   uint32_t* d_gene_len = nullptr;
-  uint32_t* d_gene_off = nullptr;
-  uint32_t* d_g2 = nullptr;
-  uint32_t* d_uf = nullptr;
-  uint32_t* d_ur = nullptr;
+  uint32_t* d_gd = nullptr;
+  uint32_t* d_ub = nullptr;
   int map_variant = 0;  // 0 = auto (seed+verify for reads <= 256), 1 = probe every window
   std::vector<std::string> fusion_seq;  // Indexer.m_fusion_seq (indexer.rs:77)
   gf_index_info info{};
@@ -104,10 +102,8 @@ struct gf_index {
     if (d_lin_base) (void)hipFree(d_lin_base);
     if (d_lin_hi) (void)hipFree(d_lin_hi);
     if (d_gene_len) (void)hipFree(d_gene_len);
-    if (d_gene_off) (void)hipFree(d_gene_off);
-    if (d_g2) (void)hipFree(d_g2);
-    if (d_uf) (void)hipFree(d_uf);
-    if (d_ur) (void)hipFree(d_ur);
+    if (d_gd) (void)hipFree(d_gd);
+    if (d_ub) (void)hipFree(d_ub);
     if (have_events) {
       (void)hipEventDestroy(ev0);
       (void)hipEventDestroy(ev1);
@@ -180,19 +176,20 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   const uint64_t nslots = (uint64_t)nbuckets * GF_SLOTS_PER_BUCKET;
 
   DevBuf<uint8_t> d_cat;
+  DevBuf<uint32_t> d_goff;
   DevBuf<unsigned long long> d_stats;
   GF_HIP(d_cat.alloc(cat_bytes));
-  GF_HIP(hipMalloc((void**)&ix->d_gene_off, ((size_t)n_genes + 1) * sizeof(uint32_t)));
+  GF_HIP(d_goff.alloc((size_t)n_genes + 1));
   GF_HIP(d_stats.alloc(8));
-  // packed genes + uniqueness bits for the diagonal verification of the mapping kernel
-  const size_t g2_words = (size_t)ntiles * (GF_TILE_BASES / 16) + 8;
-  const size_t ub_words = (size_t)ntiles * (GF_TILE_BASES / 32) + 8;
-  GF_HIP(hipMalloc((void**)&ix->d_g2, g2_words * sizeof(uint32_t)));
-  GF_HIP(hipMalloc((void**)&ix->d_uf, ub_words * sizeof(uint32_t)));
-  GF_HIP(hipMalloc((void**)&ix->d_ur, ub_words * sizeof(uint32_t)));
-  GF_HIP(hipMemset(ix->d_g2, 0, g2_words * sizeof(uint32_t)));
-  GF_HIP(hipMemset(ix->d_uf, 0, ub_words * sizeof(uint32_t)));
-  GF_HIP(hipMemset(ix->d_ur, 0, ub_words * sizeof(uint32_t)));
+  // both strands of the genes in site-code space + per-site uniqueness bits (diagonal
+  // verification of the mapping kernel); padded so that a 256-base read hanging over
+  // either end of the space stays inside the arrays
+  const size_t gd_words = (size_t)(lin_cursor / 16) + 64;
+  const size_t ub_words = (size_t)(lin_cursor / 32) + 64;
+  GF_HIP(hipMalloc((void**)&ix->d_gd, gd_words * sizeof(uint32_t)));
+  GF_HIP(hipMalloc((void**)&ix->d_ub, ub_words * sizeof(uint32_t)));
+  GF_HIP(hipMemset(ix->d_gd, 0, gd_words * sizeof(uint32_t)));
+  GF_HIP(hipMemset(ix->d_ub, 0, ub_words * sizeof(uint32_t)));
   GF_HIP(hipMalloc((void**)&ix->d_slots, nslots * sizeof(uint64_t)));
   GF_HIP(hipMalloc((void**)&ix->d_lin_base, lin_base.size() * sizeof(uint32_t)));
   GF_HIP(hipMalloc((void**)&ix->d_lin_hi, lin_hi.size() * sizeof(uint32_t)));
@@ -200,14 +197,14 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   GF_HIP(hipMemset(ix->d_slots, 0, nslots * sizeof(uint64_t)));
   GF_HIP(hipMemset(d_stats.p, 0, 8 * sizeof(unsigned long long)));
   GF_HIP(hipMemcpy(d_cat.p, cat.data(), cat_bytes, hipMemcpyHostToDevice));
-  GF_HIP(hipMemcpy(ix->d_gene_off, gene_off.data(), gene_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(d_goff.p, gene_off.data(), gene_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   GF_HIP(hipMemcpy(ix->d_lin_base, lin_base.data(), lin_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   GF_HIP(hipMemcpy(ix->d_lin_hi, lin_hi.data(), lin_hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   GF_HIP(hipMemcpy(ix->d_gene_len, glen.data(), glen.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 
   GfGenes G;
   G.cat = d_cat.p;
-  G.gene_off = ix->d_gene_off;
+  G.gene_off = d_goff.p;
   G.lin_base = ix->d_lin_base;
   G.total = (uint32_t)total;
   G.n_genes = n_genes;
@@ -237,8 +234,8 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   hipLaunchKernelGGL(gf_k_sort_dupes, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_dupes);
   GF_HIP(hipGetLastError());
   if (ntiles > 0) {
-    hipLaunchKernelGGL(gf_k_index_ubits, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G, ix->d_slots, nbuckets,
-                       ix->d_g2, ix->d_uf, ix->d_ur);
+    hipLaunchKernelGGL(gf_k_index_strands, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G, ix->d_slots, nbuckets,
+                       ix->d_gd, ix->d_ub);
     GF_HIP(hipGetLastError());
   }
   GF_HIP(hipDeviceSynchronize());
@@ -248,10 +245,8 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   ix->table.lin_base = ix->d_lin_base;
   ix->table.lin_hi = ix->d_lin_hi;
   ix->table.gene_len = ix->d_gene_len;
-  ix->table.gene_off = ix->d_gene_off;
-  ix->table.g2 = ix->d_g2;
-  ix->table.uf = ix->d_uf;
-  ix->table.ur = ix->d_ur;
+  ix->table.gd = ix->d_gd;
+  ix->table.ub = ix->d_ub;
   ix->table.nbuckets = nbuckets;
   ix->table.n_genes = n_genes;
 
@@ -266,7 +261,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   I.n_dupe_sites = (int64_t)stats[5];
   I.n_buckets = nbuckets;
   I.table_bytes = (int64_t)(nslots * sizeof(uint64_t) + std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t) +
-                            (g2_words + 2 * ub_words) * sizeof(uint32_t));
+                            (gd_words + ub_words) * sizeof(uint32_t));
   I.device = dev;
   *out_index = ix.release();
   return GF_OK;

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <vector>
 
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h;
@@ -56,7 +57,12 @@ int main(int argc, char** argv) {
   uint4* tab; uint32_t* out;
   hipMalloc((void**)&tab, bytes); hipMemset(tab, 1, bytes);
   hipMalloc((void**)&out, 64u << 20);
-  int grids[] = {256 * 4, 256 * 8, 256 * 16};
+  int grids_default[] = {256 * 4, 256 * 8, 256 * 16};
+  int grids_small[] = {32, 64, 128, 256, 512, 1024};
+  bool small = argc > 3;
+  int* grids_p = small ? grids_small : grids_default;
+  int ng = small ? 6 : 3;
+  std::vector<int> grids(grids_p, grids_p + ng);
   printf("table %d MiB, %u buckets\n", mib, nb);
   for (int g : grids) {
     printf("grid %5d:", g);
