@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgfmatch.so")
+# GFMATCH_LIB lets experiments (tools/ablate.sh) load an alternative build of the same ABI
+LIB_PATH = os.environ.get("GFMATCH_LIB") or os.path.join(_HERE, "libgfmatch.so")
 
 GF_OK = 0
 GF_ERR_ARG = -1

@@ -254,12 +254,18 @@ __device__ __forceinline__ int gf_first_pass_seed_verify(const GfTable& T, GfMap
     val[h] = 0;
   }
 
+#if defined(GF_ABLATE) && GF_ABLATE <= 2
+  return ((key[0] ^ key[1] ^ st[0] ^ (st[1] << 3)) == 0x12345677u) ? 1000 : -1;  // timing-only build: stop after key extraction
+#endif
   // seeds: windows 0, 16, 32, 48 (all inside the first probing phase)
   const bool seed = (lane & 15) == 0 && st[0] == GF_ST_UNKNOWN;
   if (seed) {
     val[0] = gf_lookup(T, key[0]);
     st[0] = GF_ST_PROBED;
   }
+#if defined(GF_ABLATE) && GF_ABLATE <= 3
+  return ((key[0] ^ key[1] ^ st[0] ^ (st[1] << 3) ^ val[0]) == 0x12345677u) ? 1000 : -1;  // timing-only: stop after the seed probes
+#endif
   int v1 = 0, v2 = 0;  // best two candidate counts (upper bounds of their final counts minus U)
   {
     const bool uniq = seed && (val[0] >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE;
@@ -297,6 +303,9 @@ __device__ __forceinline__ int gf_first_pass_seed_verify(const GfTable& T, GfMap
   const bool can1 = st[1] == GF_ST_UNKNOWN;
   const int open_votes = __popcll(__ballot(can0)) + __popcll(__ballot(can1));
   if (v1 + open_votes < GF_MAJOR_KEYS / 2 || v2 + open_votes < GF_MINOR_KEYS / 2) return -1;
+#if defined(GF_ABLATE) && GF_ABLATE <= 4
+  return ((key[0] ^ key[1] ^ st[0] ^ (st[1] << 3) ^ val[0] ^ val[1] ^ (uint32_t)v1) == 0x12345677u) ? 1000 : -1;  // timing-only
+#endif
 
   // probe what is still unknown: everything but the last 19 windows first
   const int tail0 = nwin - (GF_MAJOR_KEYS / 2 - 1);
@@ -597,8 +606,13 @@ __global__ __launch_bounds__(WAVES * 64, 8) void gf_k_map_reads_short(GfTable T,
       gf_stage_regs<LCAP>(S, cur_x0, cur_x1, ndw, lane);
       gf_wave_lds_sync();
       int nvotes;
+#if defined(GF_ABLATE) && GF_ABLATE <= 1
+      nvotes = -1;  // timing-only build: stop after staging the read in LDS
+      if (S.codes[lane & 7] == 0x12345678u) nvotes = 1000;
+#else
       if constexpr (PRODUCER == 1) nvotes = gf_first_pass_seed_verify<LCAP>(T, S, L, sh, lane);
       else nvotes = gf_first_pass_probe_all<LCAP>(T, S, L, sh, lane);
+#endif
       gf_finish_read<LCAP>(T, S, L, sh, nvotes, lane, r, counts, matches);
     }
     cur_off = nxt_off; cur_end = nxt_end; cur_x0 = nxt_x0; cur_x1 = nxt_x1;
