@@ -65,7 +65,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="first-pass producer: 0 seed+verify (default), 1 probe-all")
+    ap.add_argument("--variant", type=int, default=0, help="first pass: 0 flat pipeline (default), 1 wave-per-read probe-all, 2 wave-per-read seed+verify")
     args = ap.parse_args()
 
     import numpy as np
@@ -189,8 +189,9 @@ def main() -> None:
                 traffic = None
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": "gf_k_map_reads<256,4,%d> (%s first pass)" % (1 - args.variant,
-                                                                       "probe-all" if args.variant else "seed+verify"),
+            "kernel": ["flat pipeline: gf_k_pack + gf_k_seedverify + gf_k_probe + gf_k_map_reads_list",
+                       "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
+                       "gf_k_map_reads_short<4,1> (wave per read, seed+verify)"][args.variant],
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

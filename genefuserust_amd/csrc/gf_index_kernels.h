@@ -209,16 +209,27 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_strands(GfGenes G
       const uint64_t* s = gf_find_slot(slots, nbuckets, key);
       if (s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) {
         const uint32_t p = base + f;
-        atomicOr(ub + (p >> 5), 1u << (p & 31u));
+        atomicOr(ub + (p >> 4), 1u << (2u * (p & 15u)));
       }
     }
     if (f >= 1) {
       const uint64_t* s = gf_find_slot(slots, nbuckets, gf_revcomp_key(key));
       if (s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) {
         const uint32_t p = base - (f + 15u);
-        atomicOr(ub + (p >> 5), 1u << (p & 31u));
+        atomicOr(ub + (p >> 4), 1u << (2u * (p & 15u)));
       }
     }
+  }
+}
+
+// presence filter over every key of the table (gf_table.h: bloom)
+__global__ void gf_k_build_bloom(const uint64_t* slots, uint64_t nslots, uint32_t* bloom, uint32_t nwords) {
+  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots;
+       s += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t v = slots[s];
+    if (((uint32_t)v & GF_VAL_LOW) == 0) continue;
+    const uint32_t h2 = GF_BLOOM_H2(gf_mix32((uint32_t)(v >> 32)));
+    atomicOr(bloom + GF_BLOOM_WORD(h2, nwords), GF_BLOOM_BITS(h2));
   }
 }
 

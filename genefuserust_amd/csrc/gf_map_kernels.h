@@ -285,7 +285,7 @@ __device__ __forceinline__ int gf_first_pass_seed_verify(const GfTable& T, GfMap
         if (st[h] == GF_ST_UNKNOWN) {
           const uint32_t a = K + wi[h];
           const uint32_t gk = gf_window(T.gd[a >> 4], T.gd[(a >> 4) + 1], a);
-          const uint32_t ubit = (T.ub[a >> 5] >> (a & 31u)) & 1u;
+          const uint32_t ubit = (T.ub2[a >> 4] >> (2u * (a & 15u))) & 1u;
           ver = ubit && gk == key[h];
         }
         if (ver) {

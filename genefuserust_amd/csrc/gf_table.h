@@ -67,10 +67,23 @@ struct GfTable {
   // (the two meet at lin_base[c]; it is given to the forward strand — the reverse
   // strand's last base belongs to no indexed window, indexer.rs:188.)
   const uint32_t* gd;       // 2 bits per base, base p in bits [2(p%16), 2(p%16)+1] of word p/16
-  const uint32_t* ub;       // bit p: the site with code p exists and is the only site of its key
+  const uint32_t* ub2;      // same layout as gd; bit 2(p%16) of word p/16: the site with code p
+                            // exists and is the only site of its key
+  // presence filter consulted before a bucket probe of a window that is expected to
+  // miss (gf_pipe_kernels.h, K_probe): one 32-bit word per key, two bits inside it.
+  // Sized to stay resident in the 4 MiB L2 of each XCD, where a lookup costs a
+  // fraction of an L2-missing bucket probe.  No false negatives, so a clear bit pair
+  // proves absence; a set pair is followed by the exact bucket probe.
+  const uint32_t* bloom;
+  uint32_t bloom_words;     // 0 = filter disabled
   uint32_t nbuckets;
   int32_t n_genes;
 };
+
+// filter word and bit pair of a key, from its mixed hash h = gf_mix32(key)
+#define GF_BLOOM_H2(h) ((h) * 0x9E3779B1u)
+#define GF_BLOOM_WORD(h2, nwords) ((uint32_t)(((uint64_t)(h2) * (uint64_t)(nwords)) >> 32))
+#define GF_BLOOM_BITS(h2) ((1u << ((h2) & 31u)) | (1u << (((h2) >> 5) & 31u)))
 
 #if defined(__HIPCC__)
 #define GF_HD __host__ __device__ __forceinline__

@@ -18,6 +18,7 @@
 #include "gf_compact_kernels.h"
 #include "gf_index_kernels.h"
 #include "gf_map_kernels.h"
+#include "gf_pipe_kernels.h"
 #include "gf_table.h"
 
 static_assert(sizeof(gf_seqmatch) == 16, "gf_seqmatch layout");
@@ -86,7 +87,10 @@ struct gf_index {
   uint32_t* d_gene_len = nullptr;
   uint32_t* d_gd = nullptr;
   uint32_t* d_ub = nullptr;
-  int map_variant = 0;  // 0 = auto (seed+verify for reads <= 256), 1 = probe every window
+  uint32_t* d_bloom = nullptr;
+  // first pass for reads <= 256 bases: 0 = flat pipeline (pack, seed+verify, probe, exact
+  // kernel on survivors), 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify
+  int map_variant = 0;
   std::vector<std::string> fusion_seq;  // Indexer.m_fusion_seq (indexer.rs:77)
   gf_index_info info{};
   // profiling
@@ -104,6 +108,7 @@ struct gf_index {
     if (d_gene_len) (void)hipFree(d_gene_len);
     if (d_gd) (void)hipFree(d_gd);
     if (d_ub) (void)hipFree(d_ub);
+    if (d_bloom) (void)hipFree(d_bloom);
     if (have_events) {
       (void)hipEventDestroy(ev0);
       (void)hipEventDestroy(ev1);
@@ -185,7 +190,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   // verification of the mapping kernel); padded so that a 256-base read hanging over
   // either end of the space stays inside the arrays
   const size_t gd_words = (size_t)(lin_cursor / 16) + 64;
-  const size_t ub_words = (size_t)(lin_cursor / 32) + 64;
+  const size_t ub_words = gd_words;  // same 2-bit layout as gd
   GF_HIP(hipMalloc((void**)&ix->d_gd, gd_words * sizeof(uint32_t)));
   GF_HIP(hipMalloc((void**)&ix->d_ub, ub_words * sizeof(uint32_t)));
   GF_HIP(hipMemset(ix->d_gd, 0, gd_words * sizeof(uint32_t)));
@@ -238,15 +243,35 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
                        ix->d_gd, ix->d_ub);
     GF_HIP(hipGetLastError());
   }
+  // presence filter: L2-resident (<= GF_BLOOM_KIB, default 2 MiB), only worth having
+  // when it keeps at least ~2 bits per key
+  uint32_t bloom_words = 0;
+  {
+    size_t kib = 2048;
+    if (const char* e = getenv("GF_BLOOM_KIB")) kib = (size_t)atol(e);
+    const uint64_t want_words = std::max<uint64_t>(1024, stats[1] / 2);  // 16 bits per key
+    const uint64_t cap_words = (uint64_t)kib * 1024 / 4;
+    const uint64_t words = std::min(want_words, cap_words);
+    if (kib > 0 && words * 32 >= stats[1] * 2) {
+      bloom_words = (uint32_t)words;
+      GF_HIP(hipMalloc((void**)&ix->d_bloom, (size_t)bloom_words * sizeof(uint32_t)));
+      GF_HIP(hipMemset(ix->d_bloom, 0, (size_t)bloom_words * sizeof(uint32_t)));
+      hipLaunchKernelGGL(gf_k_build_bloom, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_bloom,
+                         bloom_words);
+      GF_HIP(hipGetLastError());
+    }
+  }
   GF_HIP(hipDeviceSynchronize());
 
   ix->table.slots = ix->d_slots;
+  ix->table.bloom = ix->d_bloom;
+  ix->table.bloom_words = bloom_words;
   ix->table.dupes = ix->d_dupes;
   ix->table.lin_base = ix->d_lin_base;
   ix->table.lin_hi = ix->d_lin_hi;
   ix->table.gene_len = ix->d_gene_len;
   ix->table.gd = ix->d_gd;
-  ix->table.ub = ix->d_ub;
+  ix->table.ub2 = ix->d_ub;
   ix->table.nbuckets = nbuckets;
   ix->table.n_genes = n_genes;
 
@@ -339,7 +364,49 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
   // each launch skips the reads of the other classes, so short reads always get the
   // small-LDS kernel with the seed+verify first pass.
   const int top = max_read_len <= 256 ? 0 : (max_read_len <= 1024 ? 1 : 2);
-  {
+  if (idx->map_variant == 0) {
+    // flat pipeline; workspace is stream-ordered so concurrent calls do not share it
+    const bool small = max_read_len <= 160;
+    const int PWs = small ? GF_PW(160) : GF_PW(256);
+    const size_t RWs = (size_t)GF_RW(PWs);
+    uint32_t* rec = nullptr;
+    GfPipeEntry* list_b = nullptr;
+    uint32_t* list_c = nullptr;
+    unsigned int* ctr = nullptr;
+    GF_HIP(hipMallocAsync((void**)&rec, (size_t)n * RWs * sizeof(uint32_t) + 64, st));
+    GF_HIP(hipMallocAsync((void**)&list_b, (size_t)n * sizeof(GfPipeEntry), st));
+    GF_HIP(hipMallocAsync((void**)&list_c, (size_t)n * sizeof(uint32_t), st));
+    GF_HIP(hipMallocAsync((void**)&ctr, 64, st));
+    GF_HIP(hipMemsetAsync(ctr, 0, 64, st));
+    const int lmax = top == 0 ? max_read_len : 256;
+    const int mark = top == 0 ? 1 : 0;
+    const int g_pack = (int)std::min<int64_t>((n * PWs + 255) / 256, (int64_t)idx->n_cus * 64);
+    const int g_sv = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 32);
+    const int g_pr = idx->n_cus * 8;
+    const int g_full = idx->n_cus * 8;
+    if (small) {
+      constexpr int PW = GF_PW(160);
+      hipLaunchKernelGGL((gf_k_pack<PW>), dim3(g_pack), dim3(256), 0, st, bases, offsets, n, -1, lmax, rec);
+      hipLaunchKernelGGL((gf_k_seedverify<PW>), dim3(g_sv), dim3(256), 0, st, idx->table, offsets, n, -1, lmax,
+                         mark, rec, counts, list_b, ctr);
+      hipLaunchKernelGGL((gf_k_probe<PW>), dim3(g_pr), dim3(256), 0, st, idx->table, rec, list_b, ctr, counts,
+                         list_c, ctr + 1);
+    } else {
+      constexpr int PW = GF_PW(256);
+      hipLaunchKernelGGL((gf_k_pack<PW>), dim3(g_pack), dim3(256), 0, st, bases, offsets, n, -1, lmax, rec);
+      hipLaunchKernelGGL((gf_k_seedverify<PW>), dim3(g_sv), dim3(256), 0, st, idx->table, offsets, n, -1, lmax,
+                         mark, rec, counts, list_b, ctr);
+      hipLaunchKernelGGL((gf_k_probe<PW>), dim3(g_pr), dim3(256), 0, st, idx->table, rec, list_b, ctr, counts,
+                         list_c, ctr + 1);
+    }
+    hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(g_full), dim3(256), 0, st, idx->table, bases, offsets,
+                       list_c, ctr + 1, counts, matches);
+    GF_HIP(hipGetLastError());
+    GF_HIP(hipFreeAsync(rec, st));
+    GF_HIP(hipFreeAsync(list_b, st));
+    GF_HIP(hipFreeAsync(list_c, st));
+    GF_HIP(hipFreeAsync(ctr, st));
+  } else {
     constexpr int W = 4;
     int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 8);
     if (idx->map_variant == 1)
@@ -519,7 +586,7 @@ int gf_in_required_direction(const gf_seqmatch* m, int32_t n, const uint8_t* gen
 }
 
 int gf_set_map_variant(gf_index* idx, int32_t variant) {
-  if (!idx || variant < 0 || variant > 1) return fail(GF_ERR_ARG, "bad variant");
+  if (!idx || variant < 0 || variant > 2) return fail(GF_ERR_ARG, "bad variant");
   idx->map_variant = variant;
   return GF_OK;
 }

@@ -237,7 +237,7 @@ class Indexer:
         _lib.check(_lib.lib().gf_set_profiling(self._handle(), int(on)))
 
     def set_map_variant(self, variant: int) -> None:
-        """0 = seed + verify first pass (default), 1 = probe every window."""
+        """0 = flat pipeline (default), 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify."""
         _lib.check(_lib.lib().gf_set_map_variant(self._handle(), int(variant)))
 
     def last_map_kernel_ms(self) -> float:

@@ -160,10 +160,11 @@ int gf_in_required_direction(const gf_seqmatch* matches, int32_t n, const uint8_
  * returns the duration of the most recent launch (negative if none). */
 int gf_set_profiling(gf_index* idx, int32_t on);
 
-/* First-pass producer of the mapping kernel for batches of reads <= 256 bases:
- * 0 (default) = seed + verify (few L2-missing requests), 1 = probe every window.
- * Both are exact and return identical results; the switch exists for A/B timing
- * and for the tests that check exactly that. */
+/* First pass for reads <= 256 bases: 0 (default) = flat pipeline (thread per read:
+ * pack, seed + verify, probe the undecided, exact wave-per-read kernel on the
+ * survivors), 1 = wave-per-read kernel probing every window, 2 = wave-per-read
+ * kernel with seed + verify.  All three are exact and return identical results;
+ * the switch exists for A/B timing and for the tests that check exactly that. */
 int gf_set_map_variant(gf_index* idx, int32_t variant);
 float gf_last_map_kernel_ms(gf_index* idx);
 

@@ -80,9 +80,9 @@ def test_index_content_every_key(branch_index, golden):
     assert not cnt.any()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_map_golden_cases(branch_index, golden, variant):
-    """variant 0 = seed+verify first pass (reads <= 256), 1 = probe every window."""
+    """variant 0 = flat pipeline, 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify."""
     branch_index.set_map_variant(variant)
     reads = [c["read"].encode() for c in golden["cases"]]
     got = branch_index.map_reads(reads)
@@ -198,7 +198,7 @@ def test_with_loaded_ref_constructor(gpu_device, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("shape,scale,n_reads", [("IDX-T", 0.02, 60000), ("IDX-C", 0.004, 60000)])
 def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, variant):
     """Repeat-rich synthetic genes (2 % repeat family, N bases) and a junction-heavy

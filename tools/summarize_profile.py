@@ -22,21 +22,27 @@ for f in find("trace/**/*kernel_stats.csv"):
             r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 for f in find("trace/**/*kernel_trace.csv"):
     rows = list(csv.DictReader(open(f)))
-    ks = [r for r in rows if "gf_k_map_reads" in r.get("Kernel_Name", "")]
-    if ks:
+    for hot in ("gf_k_map_reads", "gf_k_pack", "gf_k_seedverify", "gf_k_probe"):
+      ks = [r for r in rows if hot in r.get("Kernel_Name", "")]
+      if ks:
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ks]
         r0 = ks[0]
-        print("\n## gf_k_map_reads dispatches: n=%d avg=%.3f ms min=%.3f max=%.3f  VGPR=%s SGPR=%s LDS=%s grid=%s wg=%s" % (
+        print("\n## %s dispatches: n=%d avg=%.3f ms min=%.3f max=%.3f  VGPR=%s SGPR=%s LDS=%s grid=%s wg=%s" % (
+            r0["Kernel_Name"].split("(")[0].replace("void ", ""),
             len(d), sum(d) / len(d) / 1e6, min(d) / 1e6, max(d) / 1e6, r0.get("VGPR_Count"), r0.get("SGPR_Count"),
             r0.get("LDS_Block_Size"), r0.get("Grid_Size"), r0.get("Workgroup_Size")))
+HOT = ("gf_k_map_reads", "gf_k_pack", "gf_k_seedverify", "gf_k_probe")
 for f in find("pmc_*/**/*counter_collection.csv"):
     rows = list(csv.DictReader(open(f)))
-    acc = defaultdict(list)
+    acc = defaultdict(lambda: defaultdict(list))
     for r in rows:
-        if "gf_k_map_reads" in r.get("Kernel_Name", ""):
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    if acc:
-        print("\n## pmc (%s), per gf_k_map_reads launch (mean over %d launches)" % (
-            os.path.relpath(f, out).split(os.sep)[0], len(next(iter(acc.values())))))
-        for k, v in acc.items():
+        kn = r.get("Kernel_Name", "")
+        for h in HOT:
+            if h in kn:
+                short = kn.split("(")[0].replace("void ", "")
+                acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for kname, d in acc.items():
+        print("\n## pmc (%s) %s, per launch (mean over %d launches)" % (
+            os.path.relpath(f, out).split(os.sep)[0], kname, len(next(iter(d.values())))))
+        for k, v in d.items():
             print("  %-28s %.6g" % (k, sum(v) / len(v)))
