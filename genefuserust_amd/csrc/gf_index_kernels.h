@@ -152,13 +152,12 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_sites(GfGenes G, 
   }
 }
 
-// After FILL: publish both strands of the genes in site-code space (gd) and the
-// per-site uniqueness bits (ub) used by the mapping kernel's diagonal verification
-// (layout: gf_table.h).  gd and ub are zero-filled by the host; bits are OR-ed in.
+// After FILL: publish both strands of the genes in site-code space and the per-site
+// uniqueness flags (gdu, layout: gf_table.h) used by the diagonal verification of the
+// mapping kernels.  gdu is zero-filled by the host; bits are OR-ed in.
 __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_strands(GfGenes G, uint64_t* slots,
                                                                        uint32_t nbuckets,
-                                                                       uint32_t* __restrict__ gd,
-                                                                       uint32_t* __restrict__ ub) {
+                                                                       uint32_t* __restrict__ gdu) {
   __shared__ uint32_t s_codes[GF_TILE_BASES / 16 + 2];
   __shared__ uint32_t s_inv[GF_TILE_BASES / 32 + 2];
   const uint32_t t0 = blockIdx.x * GF_TILE_BASES;
@@ -196,10 +195,10 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_strands(GfGenes G
     const bool bad = (s_inv[l >> 5] >> (l & 31)) & 1u;
     if (!bad) {
       const uint32_t pf = base + f;
-      if (code) atomicOr(gd + (pf >> 4), code << (2 * (pf & 15u)));
+      if (code) atomicOr(gdu + 2 * (pf >> 4), code << (2 * (pf & 15u)));
       if (f >= 1) {
         const uint32_t pr = base - f;  // reverse-complement base j = len-1-f at base + 1 - len + j
-        atomicOr(gd + (pr >> 4), (code ^ 2u) << (2 * (pr & 15u)));
+        atomicOr(gdu + 2 * (pr >> 4), (code ^ 2u) << (2 * (pr & 15u)));
       }
     }
     if (f + GF_KMER > len) continue;
@@ -209,14 +208,14 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_strands(GfGenes G
       const uint64_t* s = gf_find_slot(slots, nbuckets, key);
       if (s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) {
         const uint32_t p = base + f;
-        atomicOr(ub + (p >> 4), 1u << (2u * (p & 15u)));
+        atomicOr(gdu + 2 * (p >> 4) + 1, 1u << (2u * (p & 15u)));
       }
     }
     if (f >= 1) {
       const uint64_t* s = gf_find_slot(slots, nbuckets, gf_revcomp_key(key));
       if (s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) {
         const uint32_t p = base - (f + 15u);
-        atomicOr(ub + (p >> 4), 1u << (2u * (p & 15u)));
+        atomicOr(gdu + 2 * (p >> 4) + 1, 1u << (2u * (p & 15u)));
       }
     }
   }

@@ -29,7 +29,7 @@
 // spends far fewer L2-missing requests:
 //   * 4 seed windows are probed; every UNIQUE seed hit names a candidate diagonal;
 //   * each candidate is verified against the genes themselves, stored for both
-//     strands in site-code space (gf_table.h: gd, ub): window i is *verified* when its
+//     strands in site-code space (gf_table.h: gdu): window i is *verified* when its
 //     16 bases equal the bases of site K+i and that site is flagged as the only site
 //     of its key — then the table would return exactly that one site, i.e. exactly one
 //     vote for the candidate, so the probe is skipped.  No contig decode, no strand
@@ -284,8 +284,8 @@ __device__ __forceinline__ int gf_first_pass_seed_verify(const GfTable& T, GfMap
         bool ver = false;
         if (st[h] == GF_ST_UNKNOWN) {
           const uint32_t a = K + wi[h];
-          const uint32_t gk = gf_window(T.gd[a >> 4], T.gd[(a >> 4) + 1], a);
-          const uint32_t ubit = (T.ub2[a >> 4] >> (2u * (a & 15u))) & 1u;
+          const uint32_t gk = gf_window(T.gdu[2 * (a >> 4)], T.gdu[2 * (a >> 4) + 2], a);
+          const uint32_t ubit = (T.gdu[2 * (a >> 4) + 1] >> (2u * (a & 15u))) & 1u;
           ver = ubit && gk == key[h];
         }
         if (ver) {

@@ -7,21 +7,25 @@
 // the limit.  Here every lane owns a read, so the same bookkeeping is ordinary
 // per-lane arithmetic shared by 64 reads per instruction:
 //
-//   K_pack        thread per 16 bases: ASCII -> per-read record in HBM
-//                 (2 bits per base + an "unusable base" stream in the same layout)
-//   K_seedverify  thread per read: 4 seed probes; each UNIQUE seed hit names a
-//                 candidate diagonal K; K is verified against both strands of the
-//                 genes laid out in site-code space (gf_table.h: gd, ub) with
-//                 word-parallel bit tricks (16 bases per XOR): window i counts for K
-//                 iff its 16 bases equal the bases of site K+i and that site is the
-//                 only site of its key.  Then the exact bound of gf_map_kernels.h
-//                 ("a diagonal gets at most one vote per window that can still vote"):
+//   K_pack        thread per 16 bytes of the batch: ASCII -> one packed stream in HBM
+//                 (2 bits per base, plus 1 "not A/C/G/T" bit per base), coalesced
+//                 16-byte loads, no per-read layout: a read's words are cut out of
+//                 the stream with funnel shifts by whoever needs them.
+//   K_seedverify  thread per read: up to 4 seed probes (2, then 2 more only when the
+//                 first two named no diagonal), each behind the L2-resident presence
+//                 filter; each UNIQUE seed hit names a candidate diagonal K, which is
+//                 verified against both strands of the genes laid out in site-code
+//                 space (gf_table.h: gdu) with word-parallel bit tricks (16 bases per
+//                 XOR): window i counts for K iff its 16 bases equal the bases of site
+//                 K+i and that site is the only site of its key.  Then the exact bound
+//                 of gf_map_kernels.h ("a diagonal gets at most one vote per window
+//                 that can still vote"):
 //                   v1 + open < 20 or v2 + open < 10  ->  []   (decided, nothing probed)
-//                 otherwise the read goes to K_probe with (v1, v2, verified mask).
+//                 otherwise the read goes to K_probe with (v1, v2, windows to probe).
 //   K_probe       thread per undecided read: probes its unverified windows one by one
-//                 (one 64-byte bucket per probe), h = windows that voted; stops as soon
-//                 as v1 + h + left < 20 or v2 + h + left < 10 -> [].  Reads that
-//                 survive (junction reads, repeats) go to the list for
+//                 (presence filter, then one 64-byte bucket), h = windows that voted;
+//                 stops as soon as v1 + h + left < 20 or v2 + h + left < 10 -> [].
+//                 Reads that survive (junction reads, repeats) go to the list for
 //   K_full        the wave-per-read kernel (gf_k_map_reads_list), which recomputes the
 //                 read from scratch — votes, top two, gate, second pass, segments.
 // Every read that ends here with [] was *proved* to fail the gate of
@@ -34,11 +38,11 @@
 #include "gf_map_kernels.h"
 #include "gf_table.h"
 
-// words of 16 bases per read record for reads up to LMAX bases (+1 so that a window
-// starting in the last word can always read the following word)
-#define GF_PW(LMAX) (((LMAX) + 15) / 16 + 1)
-// record = pk[PW] | iv2[PW], padded to a multiple of 4 words (16-byte vector loads)
-#define GF_RW(PW) ((2 * (PW) + 3) / 4 * 4)
+struct GfStream {
+  const uint32_t* pkg;  // word t = bases 16t..16t+15 of the stream, 2 bits each
+  const uint32_t* ivg;  // bit p = base p of the stream is not one of A,C,G,T
+  uint64_t cap_bases;   // bases covered by the two arrays
+};
 
 struct GfPipeEntry {  // one undecided read handed from K_seedverify to K_probe (32 B)
   uint32_t read;      // read index in the batch
@@ -47,71 +51,90 @@ struct GfPipeEntry {  // one undecided read handed from K_seedverify to K_probe 
   uint32_t pad[2];
 };
 
-// 4 ASCII bases (little-endian dword) -> codes in 2-bit layout + "valid" bits in the
-// same layout (bit 2k = base k is one of A,C,G,T; indexer.rs:825-841)
-__device__ __forceinline__ void gf_convert4_2bit(uint32_t x, uint32_t& code8, uint32_t& val8) {
+// stream position 0 = the 16-byte aligned address at or below the first read
+__device__ __forceinline__ uintptr_t gf_stream_origin(const uint8_t* bases, const int64_t* offsets) {
+  return (uintptr_t)(bases + offsets[0]) & ~(uintptr_t)15;
+}
+
+// 4 ASCII bases (little-endian dword) -> 8 code bits (2 per base) and 4 "bad" bits.
+// Valid bases are exactly 'A','C','G','T' (indexer.rs:825-841).
+__device__ __forceinline__ void gf_convert4_bits(uint32_t x, uint32_t& code8, uint32_t& bad4) {
   uint32_t y = (x >> 1) & 0x03030303u;
   code8 = (y * 0x01041040u) >> 24;
-  uint32_t ok = 0;
+  uint32_t bad = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     uint32_t b = (x >> (8 * j)) & 0xFFu;
     uint32_t v = (((b & 0xE0u) == 0x40u) ? 1u : 0u) & (0x0010008Au >> (b & 31u));
-    ok |= v << (8 * j);
+    bad |= (v ^ 1u) << j;
   }
-  val8 = (ok * 0x01041040u) >> 24;  // bit 0 of byte k -> bit 2k
+  bad4 = bad;
 }
 
-// ---- K_pack: thread per (read, word) ----
-template <int PW>
+// ---- K_pack: thread per 16 bytes of the batch ----
 __global__ __launch_bounds__(256) void gf_k_pack(const uint8_t* __restrict__ bases,
-                                                 const int64_t* __restrict__ offsets, int64_t n, int lmin,
-                                                 int lmax, uint32_t* __restrict__ rec) {
-  constexpr int RW = GF_RW(PW);
-  const int64_t total = n * PW;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / PW;
-    const int j = (int)(t - r * PW);
-    const int64_t off0 = offsets[r];
-    const int64_t len64 = offsets[r + 1] - off0;
-    if (len64 <= lmin || len64 > lmax) continue;  // another length class owns this read
-    const int L = (int)len64;
-    const int b0 = 16 * j;  // first base of this word
-    uint32_t pk = 0, iv = 0x55555555u;
-    if (b0 < L) {
-      const uintptr_t addr = (uintptr_t)(bases + off0 + b0);
-      const uint32_t sh = (uint32_t)(addr & 3u);
-      const uint32_t* pw = (const uint32_t*)(addr - sh);
-      const int nbytes = (L - b0) < 16 ? (L - b0) : 16;
-      const int ndw = (int)((sh + (uint32_t)nbytes + 3u) >> 2);  // aligned dwords that overlap the read
-      uint32_t d[5];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) d[k] = (k < ndw) ? pw[k] : 0u;
-      uint32_t val = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t x = sh ? __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh) : d[k];
-        uint32_t c8, v8;
-        gf_convert4_2bit(x, c8, v8);
-        pk |= c8 << (8 * k);
-        val |= v8 << (8 * k);
-      }
-      // bases at or beyond the end of the read are unusable
-      const uint32_t inside = nbytes >= 16 ? 0x55555555u : ((1u << (2 * nbytes)) - 1u) & 0x55555555u;
-      iv = (val & inside) ^ 0x55555555u;
-    }
-    rec[r * RW + j] = pk;
-    rec[r * RW + PW + j] = iv;
+                                                 const int64_t* __restrict__ offsets, int64_t n,
+                                                 uint64_t cap_chunks, uint32_t* __restrict__ pkg,
+                                                 uint16_t* __restrict__ ivg16) {
+  const uintptr_t a0 = gf_stream_origin(bases, offsets);
+  const uintptr_t end = (uintptr_t)(bases + offsets[n]);
+  uint64_t chunks = end > a0 ? (uint64_t)((end - a0 + 15) >> 4) : 0;
+  if (chunks > cap_chunks) chunks = cap_chunks;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < chunks;
+       t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 q = *(const uint4*)(a0 + 16 * t);
+    uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
+    gf_convert4_bits(q.x, c0, b0);
+    gf_convert4_bits(q.y, c1, b1);
+    gf_convert4_bits(q.z, c2, b2);
+    gf_convert4_bits(q.w, c3, b3);
+    pkg[t] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+    ivg16[t] = (uint16_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12));
   }
 }
 
-// 32 bits starting at bit position 2*p of a little-endian stream held in an unrolled
-// register array (p compile-time after unrolling)
-#define GF_STREAM_AT(arr, p) gf_window((arr)[(p) >> 4], (arr)[((p) >> 4) + 1], (uint32_t)(p))
+// 16 flag bits -> the same flags at the even bit positions of a word (2-bit layout)
+__device__ __forceinline__ uint32_t gf_spread16(uint32_t x) {
+  x &= 0xFFFFu;
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
 
-// For a stream z (bit 2p set = base p is bad), bit 2p of the result word j is set iff
-// bases p .. p+15 are all good ("a clean window starts at p").  PW-1 result words.
+// A read's words cut out of the stream: pk[j] = bases 16j..16j+15 of the read (2 bits
+// each), iv[j] = unusable-base flags in the same layout (not A/C/G/T, or beyond the end).
+template <int PW>
+__device__ __forceinline__ void gf_load_read_words(const GfStream& S, uint64_t pos, int L, uint32_t (&pk)[PW],
+                                                   uint32_t (&iv)[PW]) {
+  constexpr int IW = (PW + 1) / 2;
+  const uint64_t w0 = pos >> 4;
+  const uint32_t sh = 2u * (uint32_t)(pos & 15u);
+  uint32_t raw[PW + 1];
+#pragma unroll
+  for (int j = 0; j < PW + 1; ++j) raw[j] = S.pkg[w0 + j];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) pk[j] = sh ? ((raw[j] >> sh) | (raw[j + 1] << (32u - sh))) : raw[j];
+  const uint64_t v0 = pos >> 5;
+  const uint32_t vs = (uint32_t)(pos & 31u);
+  uint32_t rv[IW + 1];
+#pragma unroll
+  for (int j = 0; j < IW + 1; ++j) rv[j] = S.ivg[v0 + j];
+#pragma unroll
+  for (int j = 0; j < IW; ++j) {
+    uint32_t b = vs ? ((rv[j] >> vs) | (rv[j + 1] << (32u - vs))) : rv[j];
+    // bases at or beyond the end of the read are unusable
+    const int k = L - 32 * j;
+    if (k < 32) b |= k <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << k);
+    iv[2 * j] = gf_spread16(b);
+    if (2 * j + 1 < PW) iv[2 * j + 1] = gf_spread16(b >> 16);
+  }
+}
+
+// For a stream z (bit 2p set = base p is bad), bit 2p of result word j is set iff
+// bases p .. p+15 are all good ("a clean window starts at p"); bases beyond the last
+// word count as bad.
 template <int PW>
 __device__ __forceinline__ void gf_clean_windows(const uint32_t (&z)[PW], uint32_t (&out)[PW]) {
   uint32_t g[PW + 1];
@@ -124,8 +147,7 @@ __device__ __forceinline__ void gf_clean_windows(const uint32_t (&z)[PW], uint32
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
       const uint32_t sh = 2u * s;  // bits
-      const uint32_t nxt = sh == 32u ? g[j + 1] : ((g[j] >> sh) | (g[j + 1] << (32u - sh)));
-      g[j] &= nxt;
+      g[j] &= (g[j] >> sh) | (g[j + 1] << (32u - sh));
     }
   }
 #pragma unroll
@@ -141,7 +163,7 @@ __device__ __forceinline__ uint32_t gf_gather_nibble_lsb(uint32_t x) {
   return x;
 }
 
-// first bucket of a lookup with the loads issued by the caller (ILP over several keys)
+// first bucket of a lookup whose loads were issued by the caller (several in flight)
 __device__ __forceinline__ uint32_t gf_match_bucket(uint4 q0, uint4 q1, uint4 q2, uint4 q3, uint32_t key,
                                                     bool& overflow) {
   uint32_t r = 0;
@@ -157,192 +179,297 @@ __device__ __forceinline__ uint32_t gf_match_bucket(uint4 q0, uint4 q1, uint4 q2
   return r & GF_VAL_LOW;
 }
 
+// presence filter: false = the key is certainly not in the table
+__device__ __forceinline__ bool gf_maybe_present(const GfTable& T, uint32_t key) {
+  if (!T.bloom_words) return true;
+  const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key));
+  const uint32_t bits = GF_BLOOM_BITS(h2);
+  return (T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)] & bits) == bits;
+}
+
+// wave-aggregated append: returns this lane's slot when `want`, one atomic per wave
+__device__ __forceinline__ unsigned int gf_wave_append(bool want, unsigned int* counter) {
+  const uint64_t m = __ballot(want);
+  unsigned int base = 0;
+  if (m) {
+    const int leader = __builtin_ctzll(m);
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, (unsigned int)__popcll(m));
+    base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+  }
+  return base + (unsigned int)gf_lanes_below(m);
+}
+
+// block-local variant: the counter lives in LDS, slots are relative to the block's region
+__device__ __forceinline__ unsigned int gf_wave_append_lds(bool want, unsigned int* s_counter) {
+  const uint64_t m = __ballot(want);
+  unsigned int base = 0;
+  if (m) {
+    const int leader = __builtin_ctzll(m);
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(s_counter, (unsigned int)__popcll(m));
+    base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+  }
+  return base + (unsigned int)gf_lanes_below(m);
+}
+
 // ---- K_seedverify: thread per read ----
+// Block b owns the reads [b*per_block, (b+1)*per_block) and the same range of list_b:
+// its undecided reads are appended there through an LDS counter (a single global
+// counter would serialise ~300 K wave-level atomics per launch at ~90 per microsecond),
+// and blk_cnt[b] tells K_probe's block b how many entries to take.
 template <int PW>
-__global__ __launch_bounds__(256) void gf_k_seedverify(GfTable T, const int64_t* __restrict__ offsets, int64_t n,
-                                                       int lmin, int lmax, int mark_too_long,
-                                                       const uint32_t* __restrict__ rec,
+__global__ __launch_bounds__(256) void gf_k_seedverify(GfTable T, GfStream S, const uint8_t* __restrict__ bases,
+                                                       const int64_t* __restrict__ offsets, int64_t n,
+                                                       int lmax, int mark_too_long,
                                                        uint8_t* __restrict__ counts,
                                                        GfPipeEntry* __restrict__ list_b,
-                                                       unsigned int* __restrict__ n_b) {
-  constexpr int RW = GF_RW(PW);
-  constexpr int NSEED = 4;
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n;
-       r += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t len64 = offsets[r + 1] - offsets[r];
-    bool undecided = false;
-    uint32_t e_v1v2 = 0, e_mask[4] = {0, 0, 0, 0};
-    if (len64 > lmax) {
-      if (mark_too_long) counts[r] = GF_COUNT_TOO_LONG;
-    } else if (len64 <= lmin) {
-      // another length class owns this read
-    } else if (len64 < GF_KMER + 2 * (GF_MAJOR_KEYS / 2 - 1)) {
-      counts[r] = 0;  // fewer than 20 stride-2 windows: count1 < 20 whatever they hit
-    } else {
-      // the read's record: codes and unusable-base stream
-      uint32_t pk[PW], iv[PW];
-      const uint4* rp = (const uint4*)(rec + r * RW);
-      uint32_t tmp[RW];
-#pragma unroll
-      for (int q = 0; q < RW / 4; ++q) {
-        const uint4 v = rp[q];
-        tmp[4 * q] = v.x; tmp[4 * q + 1] = v.y; tmp[4 * q + 2] = v.z; tmp[4 * q + 3] = v.w;
-      }
-#pragma unroll
-      for (int j = 0; j < PW; ++j) { pk[j] = tmp[j]; iv[j] = tmp[PW + j]; }
-
-      // clean stride-2 windows of the read (all 16 bases usable): bit 4w' of word w/8
-      uint32_t cw[PW];
-      gf_clean_windows<PW>(iv, cw);
-      int nvalid = 0;
-#pragma unroll
-      for (int j = 0; j < PW - 1; ++j) nvalid += __popc(cw[j] & 0x11111111u);
-
-      // seeds at bases 0, 32, 64, 96 (word aligned: key = one record word), two
-      // probes in flight at a time
-      uint32_t cand[NSEED];
-#pragma unroll
-      for (int s0 = 0; s0 < NSEED; s0 += 2) {
-        uint4 q[2][4];
-        bool ok[2];
-        uint32_t key[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int s = s0 + u;
-          const int wj = 2 * s < PW - 1 ? 2 * s : 0;
-          ok[u] = (2 * s < PW - 1) && (cw[wj] & 1u);
-          key[u] = pk[wj];
-          const uint32_t b = gf_bucket_of(key[u], T.nbuckets);
-          const uint4* p = (const uint4*)(T.slots + (size_t)b * GF_SLOTS_PER_BUCKET);
-          if (ok[u]) { q[u][0] = p[0]; q[u][1] = p[1]; q[u][2] = p[2]; q[u][3] = p[3]; }
-          else { q[u][0] = q[u][1] = q[u][2] = q[u][3] = make_uint4(0, 0, 0, 0); }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int s = s0 + u;
-          uint32_t val = 0;
-          if (ok[u]) {
-            bool ovf;
-            val = gf_match_bucket(q[u][0], q[u][1], q[u][2], q[u][3], key[u], ovf);
-            if (ovf) val = gf_lookup(T, key[u]);  // rare: the key may live in a later bucket
-          }
-          cand[s] = ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) ? (val & GF_LIN_MASK) - 32u * s : GF_NONE_LIN;
-        }
-      }
-
-      // verify each distinct candidate diagonal
-      int v1 = 0, v2 = 0, nver = 0;
-      uint32_t vm[PW];  // verified windows, same sparse layout as cw
-#pragma unroll
-      for (int j = 0; j < PW; ++j) vm[j] = 0;
-#pragma unroll
-      for (int s = 0; s < NSEED; ++s) {
-        bool fresh = cand[s] != GF_NONE_LIN;
-#pragma unroll
-        for (int s2 = 0; s2 < s; ++s2) fresh = fresh && cand[s2] != cand[s];
-        if (fresh) {
-          const uint32_t K = cand[s];
-          const uint32_t w0 = K >> 4, bo = 2u * (K & 15u);
-          uint32_t gdr[PW + 1], ubr[PW + 1];
-#pragma unroll
-          for (int j = 0; j < PW + 1; ++j) { gdr[j] = T.gd[w0 + j]; ubr[j] = T.ub2[w0 + j]; }
-          int cnt = 0;
-#pragma unroll
-          for (int j = 0; j < PW - 1; ++j) {  // the last record word only feeds the previous one
-            const uint32_t g = bo ? ((gdr[j] >> bo) | (gdr[j + 1] << (32u - bo))) : gdr[j];
-            const uint32_t x = pk[j] ^ g;
-            const uint32_t bad = ((x | (x >> 1)) & 0x55555555u) | iv[j];
-            gdr[j] = bad;  // reuse as the "bad base" stream of this candidate
-          }
-          {
-            const int j = PW - 1;
-            const uint32_t g = bo ? ((gdr[j] >> bo) | (gdr[j + 1] << (32u - bo))) : gdr[j];
-            const uint32_t x = pk[j] ^ g;
-            gdr[j] = ((x | (x >> 1)) & 0x55555555u) | iv[j];
-          }
-          uint32_t zz[PW], cl[PW];
-#pragma unroll
-          for (int j = 0; j < PW; ++j) zz[j] = gdr[j];
-          gf_clean_windows<PW>(zz, cl);
-#pragma unroll
-          for (int j = 0; j < PW - 1; ++j) {
-            const uint32_t u = bo ? ((ubr[j] >> bo) | (ubr[j + 1] << (32u - bo))) : ubr[j];
-            const uint32_t ver = cl[j] & u & 0x11111111u & ~vm[j];
-            vm[j] |= ver;
-            cnt += __popc(ver);
-          }
-          nver += cnt;
-          if (cnt > v1) { v2 = v1; v1 = cnt; } else if (cnt > v2) { v2 = cnt; }
-        }
-      }
-
-      // every other diagonal gets at most one vote per window that can still vote
-      const int open = nvalid - nver;
-      if (v1 + open < GF_MAJOR_KEYS / 2 || v2 + open < GF_MINOR_KEYS / 2) {
-        counts[r] = 0;
+                                                       unsigned int* __restrict__ blk_cnt,
+                                                       int64_t per_block, uint32_t* __restrict__ list_c,
+                                                       unsigned int* __restrict__ ctr) {
+  __shared__ unsigned int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const uintptr_t a0 = gf_stream_origin(bases, offsets);
+  const int64_t r_lo = (int64_t)blockIdx.x * per_block;
+  const int64_t r_hi = r_lo + per_block < n ? r_lo + per_block : n;
+  GfPipeEntry* my_list = list_b + r_lo;
+  // whole waves reach the ballots: iterate in steps of the block size over a rounded range
+  for (int64_t r = r_lo + threadIdx.x; r < r_lo + ((per_block + 255) & ~(int64_t)255); r += blockDim.x) {
+    const bool in_range = r < r_hi;
+    bool undecided = false, to_full = false;
+    uint32_t e_v1v2 = 0, e_todo[4] = {0, 0, 0, 0};
+    if (in_range) {
+      const int64_t off0 = offsets[r];
+      const int64_t len64 = offsets[r + 1] - off0;
+      const uint64_t pos = (uint64_t)((uintptr_t)(bases + off0) - a0);
+      if (len64 > lmax) {
+        if (mark_too_long) counts[r] = GF_COUNT_TOO_LONG;  // else: a longer class owns this read
+      } else if (len64 < GF_KMER + 2 * (GF_MAJOR_KEYS / 2 - 1)) {
+        counts[r] = 0;  // fewer than 20 stride-2 windows: count1 < 20 whatever they hit
+      } else if (pos + (uint64_t)len64 + 64 > S.cap_bases) {
+        to_full = true;  // outside the packed stream (gaps between reads): exact kernel
       } else {
-        undecided = true;
-        e_v1v2 = (uint32_t)v1 | ((uint32_t)v2 << 8);
+        const int L = (int)len64;
+        uint32_t pk[PW], iv[PW];
+        gf_load_read_words<PW>(S, pos, L, pk, iv);
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 1
+        { uint32_t a = 0; for (int j = 0; j < PW; ++j) a ^= pk[j] ^ iv[j]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
+#endif
+
+        // clean stride-2 windows of the read (all 16 bases usable): bit 4t of word j = window 8j+t
+        uint32_t cw[PW];
+        gf_clean_windows<PW>(iv, cw);
+        int nvalid = 0;
 #pragma unroll
-        for (int j = 0; j < PW - 1; ++j) {
-          const uint32_t byte = gf_gather_nibble_lsb(cw[j] & ~vm[j]);
-          e_mask[j >> 2] |= byte << (8 * (j & 3));
+        for (int j = 0; j < PW; ++j) nvalid += __popc(cw[j] & 0x11111111u);
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 2
+        { uint32_t a = nvalid; for (int j = 0; j < PW; ++j) a ^= pk[j]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
+#endif
+
+        // seeds at bases 0, 32, 64, 96 (word aligned: the key is one word).  All four go
+        // through the presence filter together (L2 hits); the first two that pass are
+        // probed together; the others only if those named no diagonal.
+        uint32_t cand[4] = {GF_NONE_LIN, GF_NONE_LIN, GF_NONE_LIN, GF_NONE_LIN};
+        {
+          uint32_t key[4];
+          bool ok[4];
+          uint32_t fw[4], fb[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int wj = 2 * s < PW ? 2 * s : 0;
+            key[s] = pk[wj];
+            ok[s] = (2 * s < PW) && (cw[wj] & 1u);
+            if (T.bloom_words) {
+              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[s]));
+              fb[s] = GF_BLOOM_BITS(h2);
+              fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // unconditional: always in range
+            }
+          }
+          if (T.bloom_words) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ok[s] = ok[s] && (fw[s] & fb[s]) == fb[s];
+          }
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 3
+          { uint32_t a = nvalid + ok[0] + 2 * ok[1] + 4 * ok[2] + 8 * ok[3]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
+#endif
+          // round A: the first two seeds that passed; round B: the rest, if still no candidate
+          int taken = 0;
+          bool inA[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            inA[s] = ok[s] && taken < 2;
+            taken += inA[s] ? 1 : 0;
+          }
+#pragma unroll
+          for (int round = 0; round < 2; ++round) {
+            bool go[4];
+            bool any = false;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              go[s] = round == 0 ? inA[s] : (ok[s] && !inA[s]);
+              any = any || go[s];
+            }
+            if (round == 1) {
+              bool have = false;
+#pragma unroll
+              for (int s = 0; s < 4; ++s) have = have || cand[s] != GF_NONE_LIN;
+              if (have) any = false;
+            }
+            if (any) {
+              // at most two seeds go per round: two bucket images in registers
+              int iA = -1, iB = -1;
+              uint32_t kA = 0, kB = 0;
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                if (go[s]) {
+                  if (iA < 0) { iA = s; kA = key[s]; }
+                  else { iB = s; kB = key[s]; }
+                }
+              }
+              uint4 qa[4], qb[4];
+              if (iA >= 0) {  // loads only: no wait inside, so the two probes overlap
+                const uint4* p = (const uint4*)(T.slots + (size_t)gf_bucket_of(kA, T.nbuckets) * GF_SLOTS_PER_BUCKET);
+                qa[0] = p[0]; qa[1] = p[1]; qa[2] = p[2]; qa[3] = p[3];
+              }
+              if (iB >= 0) {
+                const uint4* p = (const uint4*)(T.slots + (size_t)gf_bucket_of(kB, T.nbuckets) * GF_SLOTS_PER_BUCKET);
+                qb[0] = p[0]; qb[1] = p[1]; qb[2] = p[2]; qb[3] = p[3];
+              }
+              uint32_t cA = GF_NONE_LIN, cB = GF_NONE_LIN;
+              if (iA >= 0) {
+                bool ovf;
+                uint32_t val = gf_match_bucket(qa[0], qa[1], qa[2], qa[3], kA, ovf);
+                if (ovf) val = gf_lookup(T, kA);  // rare: the key may live in a later bucket
+                if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) cA = (val & GF_LIN_MASK) - 32u * (uint32_t)iA;
+              }
+              if (iB >= 0) {
+                bool ovf;
+                uint32_t val = gf_match_bucket(qb[0], qb[1], qb[2], qb[3], kB, ovf);
+                if (ovf) val = gf_lookup(T, kB);
+                if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) cB = (val & GF_LIN_MASK) - 32u * (uint32_t)iB;
+              }
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                if (s == iA) cand[s] = cA;
+                if (s == iB) cand[s] = cB;
+              }
+            }
+          }
+        }
+
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 4
+        { uint32_t a = nvalid ^ cand[0] ^ cand[1] ^ cand[2] ^ cand[3]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
+#endif
+        // verify each distinct candidate diagonal
+        int v1 = 0, v2 = 0, nver = 0;
+        uint32_t vm[PW];  // verified windows, same sparse layout as cw
+#pragma unroll
+        for (int j = 0; j < PW; ++j) vm[j] = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bool fresh = cand[s] != GF_NONE_LIN;
+#pragma unroll
+          for (int s2 = 0; s2 < s; ++s2) fresh = fresh && cand[s2] != cand[s];
+          if (fresh) {
+            const uint32_t K = cand[s];
+            const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
+            const uint32_t bo = 2u * (K & 15u);
+            uint32_t gdr[PW + 1], ubr[PW + 1];
+#pragma unroll
+            for (int j = 0; j < PW + 1; ++j) {
+              const uint2 v = gp[j];
+              gdr[j] = v.x;
+              ubr[j] = v.y;
+            }
+            uint32_t zz[PW], cl[PW];
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+              const uint32_t g = bo ? ((gdr[j] >> bo) | (gdr[j + 1] << (32u - bo))) : gdr[j];
+              const uint32_t x = pk[j] ^ g;
+              zz[j] = ((x | (x >> 1)) & 0x55555555u) | iv[j];  // mismatching or unusable base
+            }
+            gf_clean_windows<PW>(zz, cl);
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+              const uint32_t u = bo ? ((ubr[j] >> bo) | (ubr[j + 1] << (32u - bo))) : ubr[j];
+              const uint32_t ver = cl[j] & u & 0x11111111u & ~vm[j];
+              vm[j] |= ver;
+              cnt += __popc(ver);
+            }
+            nver += cnt;
+            if (cnt > v1) { v2 = v1; v1 = cnt; } else if (cnt > v2) { v2 = cnt; }
+          }
+        }
+
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 5
+        { uint32_t a = nvalid ^ v1 ^ (v2 << 8) ^ nver; for (int j = 0; j < PW; ++j) a ^= vm[j]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
+#endif
+        // every other diagonal gets at most one vote per window that can still vote
+        const int open = nvalid - nver;
+        if (v1 + open < GF_MAJOR_KEYS / 2 || v2 + open < GF_MINOR_KEYS / 2) {
+          counts[r] = 0;
+        } else {
+          undecided = true;
+          e_v1v2 = (uint32_t)v1 | ((uint32_t)v2 << 8);
+#pragma unroll
+          for (int j = 0; j < PW; ++j)
+            e_todo[j >> 2] |= gf_gather_nibble_lsb(cw[j] & ~vm[j]) << (8 * (j & 3));
         }
       }
     }
-    // wave-aggregated append to the undecided list
-    const uint64_t m = __ballot(undecided);
-    if (m) {
-      unsigned int base = 0;
-      const int leader = __builtin_ctzll(m);
-      const int lane = threadIdx.x & 63;
-      if (lane == leader) base = atomicAdd(n_b, (unsigned int)__popcll(m));
-      base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
-      if (undecided) {
-        GfPipeEntry e;
-        e.read = (uint32_t)r;
-        e.v1v2 = e_v1v2;
-        e.todo[0] = e_mask[0]; e.todo[1] = e_mask[1]; e.todo[2] = e_mask[2]; e.todo[3] = e_mask[3];
-        e.pad[0] = e.pad[1] = 0;
-        list_b[base + gf_lanes_below(m)] = e;
-      }
+    const unsigned int slot_b = gf_wave_append_lds(undecided, &s_cnt);
+    if (undecided) {
+      GfPipeEntry e;
+      e.read = (uint32_t)r;
+      e.v1v2 = e_v1v2;
+      e.todo[0] = e_todo[0]; e.todo[1] = e_todo[1]; e.todo[2] = e_todo[2]; e.todo[3] = e_todo[3];
+      e.pad[0] = e.pad[1] = 0;
+      my_list[slot_b] = e;
     }
+    const unsigned int slot_c = gf_wave_append(to_full, ctr + 1);  // rare
+    if (to_full) list_c[slot_c] = (uint32_t)r;
   }
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt;
 }
 
 // ---- K_probe: thread per undecided read ----
 template <int PW>
-__global__ __launch_bounds__(256) void gf_k_probe(GfTable T, const uint32_t* __restrict__ rec,
+__global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const uint8_t* __restrict__ bases,
+                                                  const int64_t* __restrict__ offsets,
                                                   const GfPipeEntry* __restrict__ list_b,
-                                                  const unsigned int* __restrict__ n_b,
+                                                  const unsigned int* __restrict__ blk_cnt, int64_t per_block,
                                                   uint8_t* __restrict__ counts, uint32_t* __restrict__ list_c,
-                                                  unsigned int* __restrict__ n_c) {
-  constexpr int RW = GF_RW(PW);
+                                                  unsigned int* __restrict__ ctr) {
   // the read's codes live in LDS for the duration of its probes ([word][thread]: each
-  // thread reads only its own column, conflict-free), not in re-fetched HBM lines
-  __shared__ uint32_t s_pk[PW * 256];
-  const unsigned int nb = *n_b;
+  // thread reads only its own column, conflict-free)
+  __shared__ uint32_t s_pk[(PW + 1) * 256];
+  const uintptr_t a0 = gf_stream_origin(bases, offsets);
+  // block b takes the entries K_seedverify's block b left in its region of list_b
+  const unsigned int nb = blk_cnt[blockIdx.x];
+  const GfPipeEntry* my_list = list_b + (int64_t)blockIdx.x * per_block;
   const unsigned int nb_round = (nb + 63u) & ~63u;  // whole waves stay in the loop for the ballot
-  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < nb_round; t += gridDim.x * blockDim.x) {
+  for (unsigned int t = threadIdx.x; t < nb_round; t += blockDim.x) {
     bool to_full = false;
     uint32_t r = 0;
     if (t < nb) {
-      const GfPipeEntry e = list_b[t];
+      const GfPipeEntry e = my_list[t];
       r = e.read;
       const int v1 = (int)(e.v1v2 & 0xFFu), v2 = (int)((e.v1v2 >> 8) & 0xFFu);
       uint32_t m0 = e.todo[0], m1 = e.todo[1], m2 = e.todo[2], m3 = e.todo[3];
       int left = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
       int h = 0;
       {
-        const uint4* rp = (const uint4*)(rec + (size_t)r * RW);
+        const uint64_t pos = (uint64_t)((uintptr_t)(bases + offsets[r]) - a0);
+        const uint64_t w0 = pos >> 4;
+        const uint32_t sh = 2u * (uint32_t)(pos & 15u);
+        uint32_t raw[PW + 1];
 #pragma unroll
-        for (int q = 0; q < (PW + 3) / 4; ++q) {
-          const uint4 v = rp[q];
-          s_pk[(4 * q) * 256 + threadIdx.x] = v.x;
-          if (4 * q + 1 < PW) s_pk[(4 * q + 1) * 256 + threadIdx.x] = v.y;
-          if (4 * q + 2 < PW) s_pk[(4 * q + 2) * 256 + threadIdx.x] = v.z;
-          if (4 * q + 3 < PW) s_pk[(4 * q + 3) * 256 + threadIdx.x] = v.w;
-        }
+        for (int j = 0; j < PW + 1; ++j) raw[j] = S.pkg[w0 + j];
+#pragma unroll
+        for (int j = 0; j < PW; ++j)
+          s_pk[j * 256 + threadIdx.x] = sh ? ((raw[j] >> sh) | (raw[j + 1] << (32u - sh))) : raw[j];
+        s_pk[PW * 256 + threadIdx.x] = 0;
       }
       // count1 <= v1 + h + left and count2 <= v2 + h + left (one vote per window per diagonal)
       bool dead = (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
@@ -357,13 +484,7 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, const uint32_t* __r
         const uint32_t lo = s_pk[j * 256 + threadIdx.x], hi = s_pk[(j + 1) * 256 + threadIdx.x];
         const uint32_t key = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
         uint32_t ty = 0;
-        bool maybe = true;
-        if (T.bloom_words) {
-          const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key));
-          const uint32_t bits = GF_BLOOM_BITS(h2);
-          maybe = (T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)] & bits) == bits;
-        }
-        if (maybe) ty = gf_lookup(T, key) >> GF_TYPE_SHIFT;
+        if (gf_maybe_present(T, key)) ty = gf_lookup(T, key) >> GF_TYPE_SHIFT;
         h += (ty == GF_TYPE_UNIQUE || ty == GF_TYPE_DUPES) ? 1 : 0;
         left -= 1;
         dead = (v1 + h + left < GF_MAJOR_KEYS / 2) || (v2 + h + left < GF_MINOR_KEYS / 2);
@@ -371,15 +492,8 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, const uint32_t* __r
       if (dead) counts[r] = 0;
       else to_full = true;
     }
-    const uint64_t m = __ballot(to_full);
-    if (m) {
-      unsigned int base = 0;
-      const int leader = __builtin_ctzll(m);
-      const int lane = threadIdx.x & 63;
-      if (lane == leader) base = atomicAdd(n_c, (unsigned int)__popcll(m));
-      base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
-      if (to_full) list_c[base + gf_lanes_below(m)] = r;
-    }
+    const unsigned int slot = gf_wave_append(to_full, ctr + 1);
+    if (to_full) list_c[slot] = r;
   }
 }
 

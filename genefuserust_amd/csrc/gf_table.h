@@ -66,9 +66,10 @@ struct GfTable {
   //   reverse-complement base j (0-based)   at lin_base[c] + 1 - len_c + j
   // (the two meet at lin_base[c]; it is given to the forward strand — the reverse
   // strand's last base belongs to no indexed window, indexer.rs:188.)
-  const uint32_t* gd;       // 2 bits per base, base p in bits [2(p%16), 2(p%16)+1] of word p/16
-  const uint32_t* ub2;      // same layout as gd; bit 2(p%16) of word p/16: the site with code p
-                            // exists and is the only site of its key
+  // gdu[2k] = 16 bases (2 bits each) at positions 16k..16k+15; gdu[2k+1] = flags in the
+  // same layout, bit 2(p%16): the site with code p exists and is the only site of its
+  // key.  Interleaved so that one cache line serves both.
+  const uint32_t* gdu;
   // presence filter consulted before a bucket probe of a window that is expected to
   // miss (gf_pipe_kernels.h, K_probe): one 32-bit word per key, two bits inside it.
   // Sized to stay resident in the 4 MiB L2 of each XCD, where a lookup costs a

@@ -85,8 +85,7 @@ struct gf_index {
   uint32_t* d_lin_base = nullptr;
   uint32_t* d_lin_hi = nullptr;
   uint32_t* d_gene_len = nullptr;
-  uint32_t* d_gd = nullptr;
-  uint32_t* d_ub = nullptr;
+  uint32_t* d_gdu = nullptr;
   uint32_t* d_bloom = nullptr;
   // first pass for reads <= 256 bases: 0 = flat pipeline (pack, seed+verify, probe, exact
   // kernel on survivors), 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify
@@ -106,8 +105,7 @@ struct gf_index {
     if (d_lin_base) (void)hipFree(d_lin_base);
     if (d_lin_hi) (void)hipFree(d_lin_hi);
     if (d_gene_len) (void)hipFree(d_gene_len);
-    if (d_gd) (void)hipFree(d_gd);
-    if (d_ub) (void)hipFree(d_ub);
+    if (d_gdu) (void)hipFree(d_gdu);
     if (d_bloom) (void)hipFree(d_bloom);
     if (have_events) {
       (void)hipEventDestroy(ev0);
@@ -190,11 +188,8 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   // verification of the mapping kernel); padded so that a 256-base read hanging over
   // either end of the space stays inside the arrays
   const size_t gd_words = (size_t)(lin_cursor / 16) + 64;
-  const size_t ub_words = gd_words;  // same 2-bit layout as gd
-  GF_HIP(hipMalloc((void**)&ix->d_gd, gd_words * sizeof(uint32_t)));
-  GF_HIP(hipMalloc((void**)&ix->d_ub, ub_words * sizeof(uint32_t)));
-  GF_HIP(hipMemset(ix->d_gd, 0, gd_words * sizeof(uint32_t)));
-  GF_HIP(hipMemset(ix->d_ub, 0, ub_words * sizeof(uint32_t)));
+  GF_HIP(hipMalloc((void**)&ix->d_gdu, 2 * gd_words * sizeof(uint32_t)));
+  GF_HIP(hipMemset(ix->d_gdu, 0, 2 * gd_words * sizeof(uint32_t)));
   GF_HIP(hipMalloc((void**)&ix->d_slots, nslots * sizeof(uint64_t)));
   GF_HIP(hipMalloc((void**)&ix->d_lin_base, lin_base.size() * sizeof(uint32_t)));
   GF_HIP(hipMalloc((void**)&ix->d_lin_hi, lin_hi.size() * sizeof(uint32_t)));
@@ -240,7 +235,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   GF_HIP(hipGetLastError());
   if (ntiles > 0) {
     hipLaunchKernelGGL(gf_k_index_strands, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G, ix->d_slots, nbuckets,
-                       ix->d_gd, ix->d_ub);
+                       ix->d_gdu);
     GF_HIP(hipGetLastError());
   }
   // presence filter: L2-resident (<= GF_BLOOM_KIB, default 2 MiB), only worth having
@@ -270,8 +265,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   ix->table.lin_base = ix->d_lin_base;
   ix->table.lin_hi = ix->d_lin_hi;
   ix->table.gene_len = ix->d_gene_len;
-  ix->table.gd = ix->d_gd;
-  ix->table.ub2 = ix->d_ub;
+  ix->table.gdu = ix->d_gdu;
   ix->table.nbuckets = nbuckets;
   ix->table.n_genes = n_genes;
 
@@ -286,7 +280,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   I.n_dupe_sites = (int64_t)stats[5];
   I.n_buckets = nbuckets;
   I.table_bytes = (int64_t)(nslots * sizeof(uint64_t) + std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t) +
-                            (gd_words + ub_words) * sizeof(uint32_t));
+                            2 * gd_words * sizeof(uint32_t) + (size_t)bloom_words * sizeof(uint32_t));
   I.device = dev;
   *out_index = ix.release();
   return GF_OK;
@@ -367,44 +361,55 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
   if (idx->map_variant == 0) {
     // flat pipeline; workspace is stream-ordered so concurrent calls do not share it
     const bool small = max_read_len <= 160;
-    const int PWs = small ? GF_PW(160) : GF_PW(256);
-    const size_t RWs = (size_t)GF_RW(PWs);
-    uint32_t* rec = nullptr;
+    const int lmax = top == 0 ? max_read_len : 256;
+    const int mark = top == 0 ? 1 : 0;
+    // packed stream: covers n * lmax bases from the first read on; reads that lie beyond
+    // it (batches with gaps between reads) are routed to the exact kernel
+    const uint64_t cap_chunks = ((uint64_t)n * (uint64_t)lmax + 15) / 16 + 8;
+    uint32_t* pkg = nullptr;
+    uint32_t* ivg = nullptr;
     GfPipeEntry* list_b = nullptr;
     uint32_t* list_c = nullptr;
     unsigned int* ctr = nullptr;
-    GF_HIP(hipMallocAsync((void**)&rec, (size_t)n * RWs * sizeof(uint32_t) + 64, st));
+    GF_HIP(hipMallocAsync((void**)&pkg, (cap_chunks + 64) * sizeof(uint32_t), st));
+    GF_HIP(hipMallocAsync((void**)&ivg, (cap_chunks / 2 + 64) * sizeof(uint32_t), st));
     GF_HIP(hipMallocAsync((void**)&list_b, (size_t)n * sizeof(GfPipeEntry), st));
     GF_HIP(hipMallocAsync((void**)&list_c, (size_t)n * sizeof(uint32_t), st));
     GF_HIP(hipMallocAsync((void**)&ctr, 64, st));
     GF_HIP(hipMemsetAsync(ctr, 0, 64, st));
-    const int lmax = top == 0 ? max_read_len : 256;
-    const int mark = top == 0 ? 1 : 0;
-    const int g_pack = (int)std::min<int64_t>((n * PWs + 255) / 256, (int64_t)idx->n_cus * 64);
-    const int g_sv = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 32);
-    const int g_pr = idx->n_cus * 8;
+    GfStream S;
+    S.pkg = pkg;
+    S.ivg = ivg;
+    S.cap_bases = cap_chunks * 16;
+    const int g_pack = (int)std::min<uint64_t>((cap_chunks + 255) / 256, (uint64_t)idx->n_cus * 64);
+    // K_seedverify block b and K_probe block b share the read range / list region b
+    const int nblk = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 16);
+    const int64_t per_block = (n + nblk - 1) / nblk;
+    unsigned int* blk_cnt = nullptr;
+    GF_HIP(hipMallocAsync((void**)&blk_cnt, (size_t)nblk * sizeof(unsigned int), st));
     const int g_full = idx->n_cus * 8;
+    hipLaunchKernelGGL(gf_k_pack, dim3(g_pack), dim3(256), 0, st, bases, offsets, n, cap_chunks, pkg, (uint16_t*)ivg);
     if (small) {
-      constexpr int PW = GF_PW(160);
-      hipLaunchKernelGGL((gf_k_pack<PW>), dim3(g_pack), dim3(256), 0, st, bases, offsets, n, -1, lmax, rec);
-      hipLaunchKernelGGL((gf_k_seedverify<PW>), dim3(g_sv), dim3(256), 0, st, idx->table, offsets, n, -1, lmax,
-                         mark, rec, counts, list_b, ctr);
-      hipLaunchKernelGGL((gf_k_probe<PW>), dim3(g_pr), dim3(256), 0, st, idx->table, rec, list_b, ctr, counts,
-                         list_c, ctr + 1);
+      constexpr int PW = 10;  // 16-base words of a read of up to 160 bases
+      hipLaunchKernelGGL((gf_k_seedverify<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, n, lmax,
+                         mark, counts, list_b, blk_cnt, per_block, list_c, ctr);
+      hipLaunchKernelGGL((gf_k_probe<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, list_b,
+                         blk_cnt, per_block, counts, list_c, ctr);
     } else {
-      constexpr int PW = GF_PW(256);
-      hipLaunchKernelGGL((gf_k_pack<PW>), dim3(g_pack), dim3(256), 0, st, bases, offsets, n, -1, lmax, rec);
-      hipLaunchKernelGGL((gf_k_seedverify<PW>), dim3(g_sv), dim3(256), 0, st, idx->table, offsets, n, -1, lmax,
-                         mark, rec, counts, list_b, ctr);
-      hipLaunchKernelGGL((gf_k_probe<PW>), dim3(g_pr), dim3(256), 0, st, idx->table, rec, list_b, ctr, counts,
-                         list_c, ctr + 1);
+      constexpr int PW = 16;  // up to 256 bases
+      hipLaunchKernelGGL((gf_k_seedverify<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, n, lmax,
+                         mark, counts, list_b, blk_cnt, per_block, list_c, ctr);
+      hipLaunchKernelGGL((gf_k_probe<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, list_b,
+                         blk_cnt, per_block, counts, list_c, ctr);
     }
     hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(g_full), dim3(256), 0, st, idx->table, bases, offsets,
                        list_c, ctr + 1, counts, matches);
     GF_HIP(hipGetLastError());
-    GF_HIP(hipFreeAsync(rec, st));
+    GF_HIP(hipFreeAsync(pkg, st));
+    GF_HIP(hipFreeAsync(ivg, st));
     GF_HIP(hipFreeAsync(list_b, st));
     GF_HIP(hipFreeAsync(list_c, st));
+    GF_HIP(hipFreeAsync(blk_cnt, st));
     GF_HIP(hipFreeAsync(ctr, st));
   } else {
     constexpr int W = 4;
