@@ -58,13 +58,27 @@ __device__ __forceinline__ int gf_lanes_below(uint64_t m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+typedef uint32_t gf_u32x4 __attribute__((ext_vector_type(4)));
+
 // One probe: the 64-byte bucket of `key`.  Returns the slot's val with the
-// overflow bit cleared, 0 when the key is absent.
+// overflow bit cleared, 0 when the key is absent.  NT = load the bucket with the
+// non-temporal hint (a line that is used once should not push the L2-resident presence
+// filter out).
+template <bool NT = false>
 __device__ __forceinline__ uint32_t gf_lookup(const GfTable& T, uint32_t key) {
   uint32_t b = gf_bucket_of(key, T.nbuckets);
   for (uint32_t guard = 0; guard <= T.nbuckets; ++guard) {
     const uint4* p = (const uint4*)(T.slots + (size_t)b * GF_SLOTS_PER_BUCKET);
-    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    uint4 q0, q1, q2, q3;
+    if (NT) {
+      const gf_u32x4* pv = (const gf_u32x4*)p;
+      const gf_u32x4 a0 = __builtin_nontemporal_load(pv), a1 = __builtin_nontemporal_load(pv + 1),
+                     a2 = __builtin_nontemporal_load(pv + 2), a3 = __builtin_nontemporal_load(pv + 3);
+      q0 = make_uint4(a0.x, a0.y, a0.z, a0.w); q1 = make_uint4(a1.x, a1.y, a1.z, a1.w);
+      q2 = make_uint4(a2.x, a2.y, a2.z, a2.w); q3 = make_uint4(a3.x, a3.y, a3.z, a3.w);
+    } else {
+      q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+    }
     uint32_t r = 0;
     // slot = (key << 32) | val, little endian: .x/.z = val, .y/.w = key
     r = (q0.y == key && (q0.x & GF_VAL_LOW)) ? q0.x : r;

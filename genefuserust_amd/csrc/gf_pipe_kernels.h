@@ -38,6 +38,10 @@
 #include "gf_map_kernels.h"
 #include "gf_table.h"
 
+#ifndef GF_PROBE_NT
+#define GF_PROBE_NT false
+#endif
+
 struct GfStream {
   const uint32_t* pkg;  // word t = bases 16t..16t+15 of the stream, 2 bits each
   const uint32_t* ivg;  // bit p = base p of the stream is not one of A,C,G,T
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
         const uint32_t lo = s_pk[j * 256 + threadIdx.x], hi = s_pk[(j + 1) * 256 + threadIdx.x];
         const uint32_t key = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
         uint32_t ty = 0;
-        if (gf_maybe_present(T, key)) ty = gf_lookup(T, key) >> GF_TYPE_SHIFT;
+        if (gf_maybe_present(T, key)) ty = gf_lookup<GF_PROBE_NT>(T, key) >> GF_TYPE_SHIFT;
         h += (ty == GF_TYPE_UNIQUE || ty == GF_TYPE_DUPES) ? 1 : 0;
         left -= 1;
         dead = (v1 + h + left < GF_MAJOR_KEYS / 2) || (v2 + h + left < GF_MINOR_KEYS / 2);

@@ -238,11 +238,11 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
                        ix->d_gdu);
     GF_HIP(hipGetLastError());
   }
-  // presence filter: L2-resident (<= GF_BLOOM_KIB, default 2 MiB), only worth having
+  // presence filter: L2-resident (<= GF_BLOOM_KIB, default 3 MiB), only worth having
   // when it keeps at least ~2 bits per key
   uint32_t bloom_words = 0;
   {
-    size_t kib = 2048;
+    size_t kib = 3072;
     if (const char* e = getenv("GF_BLOOM_KIB")) kib = (size_t)atol(e);
     const uint64_t want_words = std::max<uint64_t>(1024, stats[1] / 2);  // 16 bits per key
     const uint64_t cap_words = (uint64_t)kib * 1024 / 4;
