@@ -22,9 +22,12 @@
 //                 that can still vote"):
 //                   v1 + open < 20 or v2 + open < 10  ->  []   (decided, nothing probed)
 //                 otherwise the read goes to K_probe with (v1, v2, windows to probe).
-//   K_probe       thread per undecided read: probes its unverified windows one by one
-//                 (presence filter, then one 64-byte bucket), h = windows that voted;
-//                 stops as soon as v1 + h + left < 20 or v2 + h + left < 10 -> [].
+//   K_probe       thread per undecided read.  Phase 1 asks the presence filter about every
+//                 unverified window (L2 hits only): a window the filter rules out cannot
+//                 vote, so with P windows left  v1 + P < 20 or v2 + P < 10 -> [].  Phase 2
+//                 probes the P remaining windows one by one (one 64-byte bucket each),
+//                 h = windows that voted; stops as soon as v1 + h + left < 20 or
+//                 v2 + h + left < 10 -> [].
 //                 Reads that survive (junction reads, repeats) go to the list for
 //   K_full        the wave-per-read kernel (gf_k_map_reads_list), which recomputes the
 //                 read from scratch — votes, top two, gate, second pass, segments.
@@ -475,20 +478,57 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
           s_pk[j * 256 + threadIdx.x] = sh ? ((raw[j] >> sh) | (raw[j + 1] << (32u - sh))) : raw[j];
         s_pk[PW * 256 + threadIdx.x] = 0;
       }
-      // count1 <= v1 + h + left and count2 <= v2 + h + left (one vote per window per diagonal)
+      // A window can only vote if its key is in the table, so count1 <= v1 + (windows that
+      // can vote) and count2 <= v2 + (the same).  Phase 1 asks the L2-resident presence
+      // filter about every window (4 lookups in flight, no bucket touched): a clear bit
+      // pair proves the window cannot vote.  Most undecided reads die here.
+      uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // windows the filter could not rule out
+      if (T.bloom_words) {
+        while (m0 | m1 | m2 | m3) {
+          int w[4];
+          uint32_t key[4], word[4], bits[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (m0) { w[u] = __builtin_ctz(m0); m0 &= m0 - 1; }
+            else if (m1) { w[u] = 32 + __builtin_ctz(m1); m1 &= m1 - 1; }
+            else if (m2) { w[u] = 64 + __builtin_ctz(m2); m2 &= m2 - 1; }
+            else if (m3) { w[u] = 96 + __builtin_ctz(m3); m3 &= m3 - 1; }
+            else w[u] = -1;
+            const int ww = w[u] < 0 ? 0 : w[u];
+            const int j = ww >> 3;
+            const uint32_t sh = 4u * (uint32_t)(ww & 7);
+            const uint32_t lo = s_pk[j * 256 + threadIdx.x], hi = s_pk[(j + 1) * 256 + threadIdx.x];
+            key[u] = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+            const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[u]));
+            bits[u] = GF_BLOOM_BITS(h2);
+            word[u] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // always in range
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (w[u] >= 0 && (word[u] & bits[u]) == bits[u]) {
+              const uint32_t bit = 1u << (w[u] & 31);
+              if (w[u] < 32) p0 |= bit; else if (w[u] < 64) p1 |= bit; else if (w[u] < 96) p2 |= bit; else p3 |= bit;
+            }
+          }
+        }
+      } else {
+        p0 = m0; p1 = m1; p2 = m2; p3 = m3;
+      }
+      left = __popc(p0) + __popc(p1) + __popc(p2) + __popc(p3);
+      // phase 2: the exact bucket probe of the remaining windows, one by one, stopping as
+      // soon as v1 + h + left < 20 or v2 + h + left < 10
       bool dead = (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
       while (!dead && left > 0) {
         int w;
-        if (m0) { w = __builtin_ctz(m0); m0 &= m0 - 1; }
-        else if (m1) { w = 32 + __builtin_ctz(m1); m1 &= m1 - 1; }
-        else if (m2) { w = 64 + __builtin_ctz(m2); m2 &= m2 - 1; }
-        else { w = 96 + __builtin_ctz(m3); m3 &= m3 - 1; }
+        if (p0) { w = __builtin_ctz(p0); p0 &= p0 - 1; }
+        else if (p1) { w = 32 + __builtin_ctz(p1); p1 &= p1 - 1; }
+        else if (p2) { w = 64 + __builtin_ctz(p2); p2 &= p2 - 1; }
+        else { w = 96 + __builtin_ctz(p3); p3 &= p3 - 1; }
         const int j = w >> 3;
         const uint32_t sh = 4u * (uint32_t)(w & 7);
         const uint32_t lo = s_pk[j * 256 + threadIdx.x], hi = s_pk[(j + 1) * 256 + threadIdx.x];
         const uint32_t key = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
-        uint32_t ty = 0;
-        if (gf_maybe_present(T, key)) ty = gf_lookup<GF_PROBE_NT>(T, key) >> GF_TYPE_SHIFT;
+        const uint32_t ty = gf_lookup<GF_PROBE_NT>(T, key) >> GF_TYPE_SHIFT;
         h += (ty == GF_TYPE_UNIQUE || ty == GF_TYPE_DUPES) ? 1 : 0;
         left -= 1;
         dead = (v1 + h + left < GF_MAJOR_KEYS / 2) || (v2 + h + left < GF_MINOR_KEYS / 2);
