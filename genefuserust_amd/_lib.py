@@ -108,6 +108,8 @@ def lib() -> C.CDLL:
     L.gf_in_required_direction.restype = C.c_int
     L.gf_set_profiling.argtypes = [vp, i32]
     L.gf_set_profiling.restype = C.c_int
+    L.gf_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.gf_last_stage_ms.restype = C.c_int
     L.gf_set_map_variant.argtypes = [vp, i32]
     L.gf_set_map_variant.restype = C.c_int
     L.gf_last_map_kernel_ms.argtypes = [vp]

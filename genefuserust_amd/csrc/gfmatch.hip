@@ -97,6 +97,8 @@ struct gf_index {
   bool have_events = false;
   bool recorded = false;
   hipEvent_t ev0{}, ev1{};
+  hipEvent_t ev_stage[5]{};  // pipeline stage boundaries: pack | seedverify | probe | full
+  bool stages_recorded = false;
   std::mutex prof_mu;
 
   ~gf_index() {
@@ -110,6 +112,7 @@ struct gf_index {
     if (have_events) {
       (void)hipEventDestroy(ev0);
       (void)hipEventDestroy(ev1);
+      for (auto& e : ev_stage) (void)hipEventDestroy(e);
     }
   }
 };
@@ -345,6 +348,7 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     if (!mix->have_events) {
       GF_HIP(hipEventCreate(&mix->ev0));
       GF_HIP(hipEventCreate(&mix->ev1));
+      for (auto& e : mix->ev_stage) GF_HIP(hipEventCreate(&e));
       mix->have_events = true;
     }
     GF_HIP(hipEventRecord(mix->ev0, st));
@@ -388,23 +392,32 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     unsigned int* blk_cnt = nullptr;
     GF_HIP(hipMallocAsync((void**)&blk_cnt, (size_t)nblk * sizeof(unsigned int), st));
     const int g_full = idx->n_cus * 8;
+    if (prof) GF_HIP(hipEventRecord(mix->ev_stage[0], st));
     hipLaunchKernelGGL(gf_k_pack, dim3(g_pack), dim3(256), 0, st, bases, offsets, n, cap_chunks, pkg, (uint16_t*)ivg);
+    if (prof) GF_HIP(hipEventRecord(mix->ev_stage[1], st));
     if (small) {
       constexpr int PW = 10;  // 16-base words of a read of up to 160 bases
       hipLaunchKernelGGL((gf_k_seedverify<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, n, lmax,
                          mark, counts, list_b, blk_cnt, per_block, list_c, ctr);
+      if (prof) GF_HIP(hipEventRecord(mix->ev_stage[2], st));
       hipLaunchKernelGGL((gf_k_probe<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, list_b,
                          blk_cnt, per_block, counts, list_c, ctr);
     } else {
       constexpr int PW = 16;  // up to 256 bases
       hipLaunchKernelGGL((gf_k_seedverify<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, n, lmax,
                          mark, counts, list_b, blk_cnt, per_block, list_c, ctr);
+      if (prof) GF_HIP(hipEventRecord(mix->ev_stage[2], st));
       hipLaunchKernelGGL((gf_k_probe<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, list_b,
                          blk_cnt, per_block, counts, list_c, ctr);
     }
+    if (prof) GF_HIP(hipEventRecord(mix->ev_stage[3], st));
     hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(g_full), dim3(256), 0, st, idx->table, bases, offsets,
                        list_c, ctr + 1, counts, matches);
     GF_HIP(hipGetLastError());
+    if (prof) {
+      GF_HIP(hipEventRecord(mix->ev_stage[4], st));
+      mix->stages_recorded = true;
+    }
     GF_HIP(hipFreeAsync(pkg, st));
     GF_HIP(hipFreeAsync(ivg, st));
     GF_HIP(hipFreeAsync(list_b, st));
@@ -599,6 +612,16 @@ int gf_set_map_variant(gf_index* idx, int32_t variant) {
 int gf_set_profiling(gf_index* idx, int32_t on) {
   if (!idx) return fail(GF_ERR_ARG, "null index");
   idx->profiling = on != 0;
+  return GF_OK;
+}
+
+int gf_last_stage_ms(gf_index* idx, float out[4]) {
+  if (!idx || !out) return fail(GF_ERR_ARG, "null argument");
+  if (!idx->have_events || !idx->stages_recorded) return fail(GF_ERR_ARG, "no profiled flat-pipeline call yet");
+  DeviceGuard guard(idx->device);
+  std::lock_guard<std::mutex> lk(idx->prof_mu);
+  GF_HIP(hipEventSynchronize(idx->ev_stage[4]));
+  for (int k = 0; k < 4; ++k) GF_HIP(hipEventElapsedTime(&out[k], idx->ev_stage[k], idx->ev_stage[k + 1]));
   return GF_OK;
 }
 

@@ -240,6 +240,13 @@ class Indexer:
         """0 = flat pipeline (default), 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify."""
         _lib.check(_lib.lib().gf_set_map_variant(self._handle(), int(variant)))
 
+    def last_stage_ms(self):
+        """Flat pipeline: ms of (gf_k_pack, gf_k_seedverify, gf_k_probe, gf_k_map_reads_list)."""
+        import ctypes as C
+        out = (C.c_float * 4)()
+        _lib.check(_lib.lib().gf_last_stage_ms(self._handle(), out))
+        return [float(x) for x in out]
+
     def last_map_kernel_ms(self) -> float:
         return float(_lib.lib().gf_last_map_kernel_ms(self._handle()))
 
