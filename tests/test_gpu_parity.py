@@ -314,3 +314,77 @@ def test_full_size_properties(gpu_device, oracle):
     assert (h["read_id"] == hit_idx.cpu().numpy() + 7).all()
     assert (h["n"] == counts[hit_idx].cpu().numpy()).all()
     ix.close()
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+def test_batches_with_gaps_and_mixed_lengths(branch_index, golden, oracle, variant):
+    """Reads need not be packed back to back: gaps between reads (so that most of the
+    batch lies beyond the packed stream of the flat pipeline), a first offset > 0, every
+    length class in one batch, junk bytes in the gaps."""
+    import torch
+    from tests.helpers import matches_to_tuples
+    reads = [c["read"].encode() for c in golden["cases"]]
+    want = [[tuple(m) for m in c["expect"]] for c in golden["cases"]]
+    rng = np.random.default_rng(3)
+    long1 = reads[0] * 3          # 450 bases -> 1024 class
+    long2 = (reads[3] + reads[4]) * 4  # 1200 bases -> 4096 class
+    ox = oracle.OracleIndexer([None if x is None else x.encode() for x in golden["genes"]])
+    batch = reads + [long1, long2]
+    want = want + [ox.map_read(long1), ox.map_read(long2)]
+    branch_index.set_map_variant(variant)
+    for gap in (0, 7, 400):
+        buf = bytearray(rng.integers(65, 91, size=37, dtype=np.uint8).tobytes())  # junk before the first read
+        offs = []
+        for r in batch:
+            offs.append(len(buf))
+            buf += r
+            # a read's bytes end where the next begins in `offsets`, so the junk belongs to the
+            # gap only if the offsets array skips it: emulate with zero-length "reads" = gaps
+            if gap:
+                offs.append(len(buf))
+                buf += rng.integers(65, 91, size=gap, dtype=np.uint8).tobytes()
+        offs.append(len(buf))
+        bases = np.frombuffer(bytes(buf), dtype=np.uint8)
+        offsets = np.array(offs, dtype=np.int64)
+        counts, matches = branch_index.map_reads_packed(bases, offsets)
+        got = matches_to_tuples(counts, matches)
+        if gap:
+            # odd entries are the junk "reads": random upper-case letters, map to []
+            assert all(g == [] for g in got[1::2]) or gap >= 54  # junk longer than 53 is mapped like any read
+            got = got[0::2]
+        assert got == want, (variant, gap)
+    branch_index.set_map_variant(0)
+
+
+def test_device_offsets_with_holes(branch_index, golden):
+    """Device API with an offsets array whose reads are far apart (holes the offsets skip are
+    not expressible in one array, so use long junk reads as holes and a tight max_read_len):
+    reads beyond the packed stream of the flat pipeline are routed to the exact kernel."""
+    import torch
+    from tests.helpers import matches_to_tuples
+    reads = [c["read"].encode() for c in golden["cases"][:60]]
+    want = [[tuple(m) for m in c["expect"]] for c in golden["cases"][:60]]
+    junk = b"N" * 3000
+    buf, offs = bytearray(), []
+    for r in reads:
+        offs.append(len(buf)); buf += r
+        offs.append(len(buf)); buf += junk
+    offs.append(len(buf))
+    d_b = torch.from_numpy(np.frombuffer(bytes(buf), dtype=np.uint8).copy()).cuda()
+    d_o = torch.from_numpy(np.array(offs, dtype=np.int64)).cuda()
+    # the batch limit covers the real reads only: junk entries are marked too long, and the
+    # packed stream (n * 256 bases) ends long before most real reads start
+    counts, matches = branch_index.map_reads_device(d_b, d_o, 256)
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy().astype(np.int32)
+    assert (c[1::2] == 255).all()
+    m = matches.cpu().numpy().view(np.dtype([("seq_start", "<i4"), ("seq_end", "<i4"), ("position", "<i4"),
+                                            ("contig", "<i2"), ("pad", "<i2")])).reshape(-1, 2)
+    lens = np.array([len(r) for r in reads])
+    cr = c[0::2].copy()
+    assert (cr[lens > 256] == 255).all()
+    cr[lens > 256] = 0
+    got = matches_to_tuples(cr, m[0::2])
+    for k, (g, w, ln) in enumerate(zip(got, want, lens)):
+        if ln <= 256:
+            assert g == w, k
