@@ -84,11 +84,19 @@ def main() -> None:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (gfmatch has no CPU fallback)")
+    # GF_BENCH_REHEARSAL=1: every rank uses cuda:0 and the collective runs on gloo — only to
+    # exercise the N>1 code path on a one-GPU box; never a measurement
+    rehearsal = os.environ.get("GF_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
         if world > 1:
@@ -170,7 +178,7 @@ def main() -> None:
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u32",
-        "data": "synthetic",
+        "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL on one GPU over gloo: not a measurement)",
         "config": {
             "workload": "BASELINE configs[1]: %d synthetic %d-bp read pairs (%d reads) per GPU vs %s "
                         "(druggable.hg38-shaped: first 32 gene spans of testdata/cancer.csv, %d bp), mix %s"

@@ -37,6 +37,9 @@ def allgather_hits(hits: torch.Tensor, n_hits: torch.Tensor, group=None) -> torc
     world = dist.get_world_size(group)
     if world == 1:
         return hits[: int(n_hits.item())]
+    if hits.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal on a box without RCCL peers: stage through the host
+        return allgather_hits(hits.cpu(), n_hits.cpu(), group).to(hits.device)
     counts = torch.empty(world, dtype=torch.int64, device=hits.device)
     dist.all_gather_into_tensor(counts, n_hits.reshape(1), group=group)
     counts_h = counts.cpu()
