@@ -483,8 +483,10 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
       // filter about every window (4 lookups in flight, no bucket touched): a clear bit
       // pair proves the window cannot vote.  Most undecided reads die here.
       uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // windows the filter could not rule out
+      bool dead = false;
       if (T.bloom_words) {
-        while (m0 | m1 | m2 | m3) {
+        int npos = 0, rem = left;  // not ruled out so far / not asked yet
+        while ((m0 | m1 | m2 | m3) && !dead) {
           int w[4];
           uint32_t key[4], word[4], bits[4];
 #pragma unroll
@@ -505,11 +507,15 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
+            rem -= w[u] >= 0 ? 1 : 0;
             if (w[u] >= 0 && (word[u] & bits[u]) == bits[u]) {
               const uint32_t bit = 1u << (w[u] & 31);
               if (w[u] < 32) p0 |= bit; else if (w[u] < 64) p1 |= bit; else if (w[u] < 96) p2 |= bit; else p3 |= bit;
+              npos += 1;
             }
           }
+          // even if every window not asked yet could vote, the gate is out of reach
+          dead = (v1 + npos + rem < GF_MAJOR_KEYS / 2) || (v2 + npos + rem < GF_MINOR_KEYS / 2);
         }
       } else {
         p0 = m0; p1 = m1; p2 = m2; p3 = m3;
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
       left = __popc(p0) + __popc(p1) + __popc(p2) + __popc(p3);
       // phase 2: the exact bucket probe of the remaining windows, one by one, stopping as
       // soon as v1 + h + left < 20 or v2 + h + left < 10
-      bool dead = (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
+      dead = dead || (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
       while (!dead && left > 0) {
         int w;
         if (p0) { w = __builtin_ctz(p0); p0 &= p0 - 1; }
