@@ -525,18 +525,40 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
       // soon as v1 + h + left < 20 or v2 + h + left < 10
       dead = dead || (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
       while (!dead && left > 0) {
-        int w;
-        if (p0) { w = __builtin_ctz(p0); p0 &= p0 - 1; }
-        else if (p1) { w = 32 + __builtin_ctz(p1); p1 &= p1 - 1; }
-        else if (p2) { w = 64 + __builtin_ctz(p2); p2 &= p2 - 1; }
-        else { w = 96 + __builtin_ctz(p3); p3 &= p3 - 1; }
-        const int j = w >> 3;
-        const uint32_t sh = 4u * (uint32_t)(w & 7);
-        const uint32_t lo = s_pk[j * 256 + threadIdx.x], hi = s_pk[(j + 1) * 256 + threadIdx.x];
-        const uint32_t key = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
-        const uint32_t ty = gf_lookup<GF_PROBE_NT>(T, key) >> GF_TYPE_SHIFT;
-        h += (ty == GF_TYPE_UNIQUE || ty == GF_TYPE_DUPES) ? 1 : 0;
-        left -= 1;
+        // the read dies only after at least `need` more probes miss: issue that many (up to
+        // 4) bucket probes together instead of one round trip each
+        const int needA = v1 + h + left - (GF_MAJOR_KEYS / 2 - 1);
+        const int needB = v2 + h + left - (GF_MINOR_KEYS / 2 - 1);
+        int need = needA < needB ? needA : needB;
+        need = need < 1 ? 1 : (need > 4 ? 4 : need);
+        uint32_t key[4];
+        bool act[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          act[u] = u < need && (p0 | p1 | p2 | p3);
+          int w = 0;
+          if (act[u]) {
+            if (p0) { w = __builtin_ctz(p0); p0 &= p0 - 1; }
+            else if (p1) { w = 32 + __builtin_ctz(p1); p1 &= p1 - 1; }
+            else if (p2) { w = 64 + __builtin_ctz(p2); p2 &= p2 - 1; }
+            else { w = 96 + __builtin_ctz(p3); p3 &= p3 - 1; }
+          }
+          const int j = w >> 3;
+          const uint32_t sh = 4u * (uint32_t)(w & 7);
+          const uint32_t lo = s_pk[j * 256 + threadIdx.x], hi = s_pk[(j + 1) * 256 + threadIdx.x];
+          key[u] = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+        }
+        uint32_t ty[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (act[u]) ty[u] = gf_lookup<GF_PROBE_NT>(T, key[u]) >> GF_TYPE_SHIFT;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (act[u]) {
+            h += (ty[u] == GF_TYPE_UNIQUE || ty[u] == GF_TYPE_DUPES) ? 1 : 0;
+            left -= 1;
+          }
+        }
         dead = (v1 + h + left < GF_MAJOR_KEYS / 2) || (v2 + h + left < GF_MINOR_KEYS / 2);
       }
       if (dead) counts[r] = 0;

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -96,6 +97,14 @@ struct gf_index {
   bool profiling = false;
   bool have_events = false;
   bool recorded = false;
+  // per-stream workspace of the flat pipeline (grow-only).  Calls on one stream run in
+  // order, so the next call may reuse the buffers; launch sequences are serialised by
+  // ws_mu so that two host threads sharing a stream cannot interleave their kernels.
+  // (Stream-ordered hipMallocAsync/hipFreeAsync was tried first: on the legacy default
+  // stream a free issued right after the launches raced with the kernels.)
+  struct Workspace { void* base = nullptr; size_t bytes = 0; };
+  std::map<hipStream_t, Workspace> ws;
+  std::mutex ws_mu;
   hipEvent_t ev0{}, ev1{};
   hipEvent_t ev_stage[5]{};  // pipeline stage boundaries: pack | seedverify | probe | full
   bool stages_recorded = false;
@@ -109,6 +118,8 @@ struct gf_index {
     if (d_gene_len) (void)hipFree(d_gene_len);
     if (d_gdu) (void)hipFree(d_gdu);
     if (d_bloom) (void)hipFree(d_bloom);
+    for (auto& kv : ws)
+      if (kv.second.base) (void)hipFree(kv.second.base);
     if (have_events) {
       (void)hipEventDestroy(ev0);
       (void)hipEventDestroy(ev1);
@@ -140,6 +151,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
 
   std::unique_ptr<gf_index> ix(new gf_index());
   ix->device = dev;
+  if (const char* e = getenv("GF_MAP_VARIANT")) ix->map_variant = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;  // experiments
   hipDeviceProp_t prop;
   GF_HIP(hipGetDeviceProperties(&prop, dev));
   ix->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -363,23 +375,42 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
   // small-LDS kernel with the seed+verify first pass.
   const int top = max_read_len <= 256 ? 0 : (max_read_len <= 1024 ? 1 : 2);
   if (idx->map_variant == 0) {
-    // flat pipeline; workspace is stream-ordered so concurrent calls do not share it
+    // flat pipeline
     const bool small = max_read_len <= 160;
     const int lmax = top == 0 ? max_read_len : 256;
     const int mark = top == 0 ? 1 : 0;
     // packed stream: covers n * lmax bases from the first read on; reads that lie beyond
     // it (batches with gaps between reads) are routed to the exact kernel
     const uint64_t cap_chunks = ((uint64_t)n * (uint64_t)lmax + 15) / 16 + 8;
-    uint32_t* pkg = nullptr;
-    uint32_t* ivg = nullptr;
-    GfPipeEntry* list_b = nullptr;
-    uint32_t* list_c = nullptr;
-    unsigned int* ctr = nullptr;
-    GF_HIP(hipMallocAsync((void**)&pkg, (cap_chunks + 64) * sizeof(uint32_t), st));
-    GF_HIP(hipMallocAsync((void**)&ivg, (cap_chunks / 2 + 64) * sizeof(uint32_t), st));
-    GF_HIP(hipMallocAsync((void**)&list_b, (size_t)n * sizeof(GfPipeEntry), st));
-    GF_HIP(hipMallocAsync((void**)&list_c, (size_t)n * sizeof(uint32_t), st));
-    GF_HIP(hipMallocAsync((void**)&ctr, 64, st));
+    const int nblk = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 16);
+    const int64_t per_block = (n + nblk - 1) / nblk;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t sz_pkg = al((cap_chunks + 64) * sizeof(uint32_t));
+    const size_t sz_ivg = al((cap_chunks / 2 + 64) * sizeof(uint32_t));
+    const size_t sz_lb = al((size_t)n * sizeof(GfPipeEntry));
+    const size_t sz_lc = al((size_t)n * sizeof(uint32_t));
+    const size_t sz_bc = al((size_t)nblk * sizeof(unsigned int));
+    const size_t sz_ctr = 256;
+    const size_t need = sz_pkg + sz_ivg + sz_lb + sz_lc + sz_bc + sz_ctr;
+    std::lock_guard<std::mutex> ws_lock(mix->ws_mu);  // held until this call's launches are queued
+    gf_index::Workspace& W = mix->ws[st];
+    if (W.bytes < need) {
+      if (W.base) {
+        GF_HIP(hipStreamSynchronize(st));  // earlier calls on this stream may still use it
+        GF_HIP(hipFree(W.base));
+        W.base = nullptr;
+        W.bytes = 0;
+      }
+      GF_HIP(hipMalloc(&W.base, need));
+      W.bytes = need;
+    }
+    uint8_t* wp = (uint8_t*)W.base;
+    uint32_t* pkg = (uint32_t*)wp; wp += sz_pkg;
+    uint32_t* ivg = (uint32_t*)wp; wp += sz_ivg;
+    GfPipeEntry* list_b = (GfPipeEntry*)wp; wp += sz_lb;
+    uint32_t* list_c = (uint32_t*)wp; wp += sz_lc;
+    unsigned int* blk_cnt = (unsigned int*)wp; wp += sz_bc;
+    unsigned int* ctr = (unsigned int*)wp;
     GF_HIP(hipMemsetAsync(ctr, 0, 64, st));
     GfStream S;
     S.pkg = pkg;
@@ -387,10 +418,6 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     S.cap_bases = cap_chunks * 16;
     const int g_pack = (int)std::min<uint64_t>((cap_chunks + 255) / 256, (uint64_t)idx->n_cus * 64);
     // K_seedverify block b and K_probe block b share the read range / list region b
-    const int nblk = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 16);
-    const int64_t per_block = (n + nblk - 1) / nblk;
-    unsigned int* blk_cnt = nullptr;
-    GF_HIP(hipMallocAsync((void**)&blk_cnt, (size_t)nblk * sizeof(unsigned int), st));
     const int g_full = idx->n_cus * 8;
     if (prof) GF_HIP(hipEventRecord(mix->ev_stage[0], st));
     hipLaunchKernelGGL(gf_k_pack, dim3(g_pack), dim3(256), 0, st, bases, offsets, n, cap_chunks, pkg, (uint16_t*)ivg);
@@ -418,12 +445,6 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
       GF_HIP(hipEventRecord(mix->ev_stage[4], st));
       mix->stages_recorded = true;
     }
-    GF_HIP(hipFreeAsync(pkg, st));
-    GF_HIP(hipFreeAsync(ivg, st));
-    GF_HIP(hipFreeAsync(list_b, st));
-    GF_HIP(hipFreeAsync(list_c, st));
-    GF_HIP(hipFreeAsync(blk_cnt, st));
-    GF_HIP(hipFreeAsync(ctr, st));
   } else {
     constexpr int W = 4;
     int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 8);

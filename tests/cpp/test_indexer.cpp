@@ -52,6 +52,11 @@ int main() {
   EXPECT(m[1].seq_start == 75 && m[1].seq_end == 149 && m[1].start_gp.contig == 1 && m[1].start_gp.position == q - 75);
   EXPECT(ix.in_required_direction(m));  // left forward gene, right reversed gene (indexer.rs:578-590)
   auto mr = ix.map_read(rc(read));
+  if (mr.size() != 2 || mr[0].seq_start != 75) {
+    printf("rc read: %zu matches", mr.size());
+    for (auto& x : mr) printf(" [%d-%d|%d:%d]", x.seq_start, x.seq_end, x.start_gp.contig, x.start_gp.position);
+    printf(" expected [75-149|0:%d] [0-74|1:%d]\n", -(p + 75), -(q + 74));
+  }
   EXPECT(mr.size() == 2 && mr[0].seq_start == 75 && mr[0].start_gp.position == -(p + 75));
   EXPECT(mr[1].start_gp.contig == 1 && mr[1].start_gp.position == -(q + 74));
   EXPECT(!ix.in_required_direction(mr));

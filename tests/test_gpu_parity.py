@@ -388,3 +388,15 @@ def test_device_offsets_with_holes(branch_index, golden):
     for k, (g, w, ln) in enumerate(zip(got, want, lens)):
         if ln <= 256:
             assert g == w, k
+
+
+def test_single_read_calls_are_stable(branch_index, golden):
+    """Indexer::map_read is called one read at a time by the reference; 400 back-to-back
+    n = 1 calls (tiny kernels, workspace reused immediately) must keep returning the golden
+    answers.  Regression: a stream-ordered free used to race with the kernels here."""
+    cases = [c for c in golden["cases"] if c["expect"]][:20]
+    for rep in range(20):
+        for c in cases:
+            got = branch_index.map_read(c["read"])
+            flat = [(m.seq_start, m.seq_end, m.start_gp.contig, m.start_gp.position) for m in got]
+            assert flat == [tuple(m) for m in c["expect"]], (rep, c["label"])
