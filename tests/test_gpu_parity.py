@@ -163,6 +163,27 @@ def test_edge_batches(branch_index, gpu_device, oracle):
     with pytest.raises(_lib.GfError) as e:
         branch_index.map_read(b"A" * 5000)
     assert e.value.code == _lib.GF_ERR_READ_TOO_LONG
+    with pytest.raises(_lib.GfError):
+        branch_index.map_read(b"A" * (_lib.GF_MAX_READ_LEN + 1))
+    # maximum size: a read of exactly GF_MAX_READ_LEN bases stitched from two genes
+    g = [x for x in branch_index.m_fusion_seq[:2]]
+    big = (g[0][100:2100] + g[1][200:2296]).encode()
+    assert len(big) == _lib.GF_MAX_READ_LEN
+    ox_genes = [s.encode() if s else None for s in branch_index.m_fusion_seq]
+    want = oracle.OracleIndexer(ox_genes).map_read(big)
+    got = [(m.seq_start, m.seq_end, m.start_gp.contig, m.start_gp.position) for m in branch_index.map_read(big)]
+    assert got == want
+    # the same on repeat-free genes, where the maximum-size read really yields two segments
+    rng = np.random.default_rng(77)
+    clean = [rand_seq(rng, 3000), rand_seq(rng, 3000)]
+    ixc = Indexer.from_gene_slices(clean)
+    ixc.make_index()
+    big = clean[0][10:2058] + clean[1][500:2548]
+    assert len(big) == _lib.GF_MAX_READ_LEN
+    want = oracle.OracleIndexer(clean).map_read(big)
+    got = [(m.seq_start, m.seq_end, m.start_gp.contig, m.start_gp.position) for m in ixc.map_read(big)]
+    assert got == want and len(want) == 2
+    ixc.close()
     # BASELINE config 1 plumbing: every gene unresolved -> empty index -> every read []
     ix = Indexer.from_gene_slices([None, None, None, None])
     ix.make_index()
@@ -198,14 +219,17 @@ def test_with_loaded_ref_constructor(gpu_device, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, "0-nofilter"])
 @pytest.mark.parametrize("shape,scale,n_reads", [("IDX-T", 0.02, 60000), ("IDX-C", 0.004, 60000)])
-def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, variant):
+def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, variant, monkeypatch):
     """Repeat-rich synthetic genes (2 % repeat family, N bases) and a junction-heavy
     read mix: every read's SeqMatch list equals the oracle's."""
     from genefuserust_amd import Indexer
     from genefuserust_amd import synth
     genes = synth.make_geneset(shape, scale=scale)
+    if variant == "0-nofilter":  # indexes too large for an L2-resident presence filter take this path
+        monkeypatch.setenv("GF_BLOOM_KIB", "0")
+        variant = 0
     ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
     ix.make_index()
     ix.set_map_variant(variant)
