@@ -221,14 +221,16 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_strands(GfGenes G
   }
 }
 
-// presence filter over every key of the table (gf_table.h: bloom)
+// presence filter over the last and the first 14 bases of every key (gf_table.h: bloom)
 __global__ void gf_k_build_bloom(const uint64_t* slots, uint64_t nslots, uint32_t* bloom, uint32_t nwords) {
   for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots;
        s += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t v = slots[s];
     if (((uint32_t)v & GF_VAL_LOW) == 0) continue;
-    const uint32_t h2 = GF_BLOOM_H2(gf_mix32((uint32_t)(v >> 32)));
-    atomicOr(bloom + GF_BLOOM_WORD(h2, nwords), GF_BLOOM_BITS(h2));
+    const uint32_t key = (uint32_t)(v >> 32);
+    const uint32_t ha = GF_BLOOM_H2(gf_mix32(key >> 4)), hb = GF_BLOOM_H2(gf_mix32(key & 0x0FFFFFFFu));
+    atomicOr(bloom + GF_BLOOM_WORD(ha, nwords), GF_BLOOM_BITS(ha));
+    atomicOr(bloom + GF_BLOOM_WORD(hb, nwords), GF_BLOOM_BITS(hb));
   }
 }
 

@@ -23,8 +23,9 @@
 //                   v1 + open < 20 or v2 + open < 10  ->  []   (decided, nothing probed)
 //                 otherwise the read goes to K_probe with (v1, v2, windows to probe).
 //   K_probe       thread per undecided read.  Phase 1 asks the presence filter about every
-//                 unverified window (L2 hits only): a window the filter rules out cannot
-//                 vote, so with P windows left  v1 + P < 20 or v2 + P < 10 -> [].  Phase 2
+//                 unverified window, two windows per lookup (they share a 14-mer; L2 hits
+//                 only): a window the filter rules out cannot vote, so with P windows left
+//                 v1 + P < 20 or v2 + P < 10 -> [].  Phase 2
 //                 probes the P remaining windows one by one (one 64-byte bucket each),
 //                 h = windows that voted; stops as soon as v1 + h + left < 20 or
 //                 v2 + h + left < 10 -> [].
@@ -186,14 +187,6 @@ __device__ __forceinline__ uint32_t gf_match_bucket(uint4 q0, uint4 q1, uint4 q2
   return r & GF_VAL_LOW;
 }
 
-// presence filter: false = the key is certainly not in the table
-__device__ __forceinline__ bool gf_maybe_present(const GfTable& T, uint32_t key) {
-  if (!T.bloom_words) return true;
-  const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key));
-  const uint32_t bits = GF_BLOOM_BITS(h2);
-  return (T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)] & bits) == bits;
-}
-
 // wave-aggregated append: returns this lane's slot when `want`, one atomic per wave
 __device__ __forceinline__ unsigned int gf_wave_append(bool want, unsigned int* counter) {
   const uint64_t m = __ballot(want);
@@ -286,7 +279,7 @@ __global__ __launch_bounds__(256) void gf_k_seedverify(GfTable T, GfStream S, co
             key[s] = pk[wj];
             ok[s] = (2 * s < PW) && (cw[wj] & 1u);
             if (T.bloom_words) {
-              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[s]));
+              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[s] >> 4));  // the window's last 14 bases
               fb[s] = GF_BLOOM_BITS(h2);
               fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // unconditional: always in range
             }
@@ -485,33 +478,42 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
       uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // windows the filter could not rule out
       bool dead = false;
       if (T.bloom_words) {
+        // windows 2q and 2q+1 share the 14-mer at bases 4q+2 .. 4q+15: one lookup for both
+        uint32_t pr[4] = {(m0 | (m0 >> 1)) & 0x55555555u, (m1 | (m1 >> 1)) & 0x55555555u,
+                          (m2 | (m2 >> 1)) & 0x55555555u, (m3 | (m3 >> 1)) & 0x55555555u};
+        const uint32_t td[4] = {m0, m1, m2, m3};
         int npos = 0, rem = left;  // not ruled out so far / not asked yet
-        while ((m0 | m1 | m2 | m3) && !dead) {
-          int w[4];
-          uint32_t key[4], word[4], bits[4];
+        while ((pr[0] | pr[1] | pr[2] | pr[3]) && !dead) {
+          int w[4];  // even window of each pair, -1 = none
+          uint32_t word[4], bits[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            if (m0) { w[u] = __builtin_ctz(m0); m0 &= m0 - 1; }
-            else if (m1) { w[u] = 32 + __builtin_ctz(m1); m1 &= m1 - 1; }
-            else if (m2) { w[u] = 64 + __builtin_ctz(m2); m2 &= m2 - 1; }
-            else if (m3) { w[u] = 96 + __builtin_ctz(m3); m3 &= m3 - 1; }
+            if (pr[0]) { w[u] = __builtin_ctz(pr[0]); pr[0] &= pr[0] - 1; }
+            else if (pr[1]) { w[u] = 32 + __builtin_ctz(pr[1]); pr[1] &= pr[1] - 1; }
+            else if (pr[2]) { w[u] = 64 + __builtin_ctz(pr[2]); pr[2] &= pr[2] - 1; }
+            else if (pr[3]) { w[u] = 96 + __builtin_ctz(pr[3]); pr[3] &= pr[3] - 1; }
             else w[u] = -1;
             const int ww = w[u] < 0 ? 0 : w[u];
-            const int j = ww >> 3;
-            const uint32_t sh = 4u * (uint32_t)(ww & 7);
+            const int b0 = 2 * ww + 2;  // first base of the shared 14-mer
+            const int j = b0 >> 4;
+            const uint32_t sh = 2u * (uint32_t)(b0 & 15);
             const uint32_t lo = s_pk[j * 256 + threadIdx.x], hi = s_pk[(j + 1) * 256 + threadIdx.x];
-            key[u] = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
-            const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[u]));
+            const uint32_t s14 = (sh ? ((lo >> sh) | (hi << (32u - sh))) : lo) & 0x0FFFFFFFu;
+            const uint32_t h2 = GF_BLOOM_H2(gf_mix32(s14));
             bits[u] = GF_BLOOM_BITS(h2);
             word[u] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // always in range
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            rem -= w[u] >= 0 ? 1 : 0;
-            if (w[u] >= 0 && (word[u] & bits[u]) == bits[u]) {
-              const uint32_t bit = 1u << (w[u] & 31);
-              if (w[u] < 32) p0 |= bit; else if (w[u] < 64) p1 |= bit; else if (w[u] < 96) p2 |= bit; else p3 |= bit;
-              npos += 1;
+            if (w[u] >= 0) {
+              const uint32_t both = (td[w[u] >> 5] >> (w[u] & 31)) & 3u;  // which of the pair are to do
+              const int cnt = (int)(both & 1u) + (int)(both >> 1);
+              rem -= cnt;
+              if ((word[u] & bits[u]) == bits[u]) {
+                const uint32_t bit = both << (w[u] & 31);
+                if (w[u] < 32) p0 |= bit; else if (w[u] < 64) p1 |= bit; else if (w[u] < 96) p2 |= bit; else p3 |= bit;
+                npos += cnt;
+              }
             }
           }
           // even if every window not asked yet could vote, the gate is out of reach

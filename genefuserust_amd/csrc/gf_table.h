@@ -70,18 +70,20 @@ struct GfTable {
   // same layout, bit 2(p%16): the site with code p exists and is the only site of its
   // key.  Interleaved so that one cache line serves both.
   const uint32_t* gdu;
-  // presence filter consulted before a bucket probe of a window that is expected to
-  // miss (gf_pipe_kernels.h, K_probe): one 32-bit word per key, two bits inside it.
-  // Sized to stay resident in the 4 MiB L2 of each XCD, where a lookup costs a
-  // fraction of an L2-missing bucket probe.  No false negatives, so a clear bit pair
-  // proves absence; a set pair is followed by the exact bucket probe.
+  // presence filter over 14-mers (one 32-bit word, two bits per element), consulted
+  // before any bucket probe of a window that is expected to miss.  For every key of the
+  // table its last 14 bases (key >> 4) and its first 14 bases (key & 0x0FFFFFFF) are
+  // inserted.  Two consecutive stride-2 windows w, w+1 share the 14-mer S = bases 2..15 of
+  // w = bases 0..13 of w+1, so ONE lookup of S answers for both: S absent => neither
+  // window's key is in the table (no false negatives).  Sized to stay resident in the
+  // 4 MiB L2 of each XCD, where a lookup costs a fraction of an L2-missing bucket probe.
   const uint32_t* bloom;
   uint32_t bloom_words;     // 0 = filter disabled
   uint32_t nbuckets;
   int32_t n_genes;
 };
 
-// filter word and bit pair of a key, from its mixed hash h = gf_mix32(key)
+// filter word and bit pair of a 14-mer x (28 bits), from its mixed hash h = gf_mix32(x)
 #define GF_BLOOM_H2(h) ((h) * 0x9E3779B1u)
 #define GF_BLOOM_WORD(h2, nwords) ((uint32_t)(((uint64_t)(h2) * (uint64_t)(nwords)) >> 32))
 #define GF_BLOOM_BITS(h2) ((1u << ((h2) & 31u)) | (1u << (((h2) >> 5) & 31u)))
