@@ -266,8 +266,7 @@ __global__ __launch_bounds__(256) void gf_k_seedverify(GfTable T, GfStream S, co
 #endif
 
         // seeds at bases 0, 32, 64, 96 (word aligned: the key is one word).  All four go
-        // through the presence filter together (L2 hits); the first two that pass are
-        // probed together; the others only if those named no diagonal.
+        // through the presence filter together (L2 hits).
         uint32_t cand[4] = {GF_NONE_LIN, GF_NONE_LIN, GF_NONE_LIN, GF_NONE_LIN};
         {
           uint32_t key[4];
@@ -291,74 +290,20 @@ __global__ __launch_bounds__(256) void gf_k_seedverify(GfTable T, GfStream S, co
 #if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 3
           { uint32_t a = nvalid + ok[0] + 2 * ok[1] + 4 * ok[2] + 8 * ok[3]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
 #endif
-          // round A: the first two seeds that passed; round B: the rest, if still no candidate
-          int taken = 0;
-          bool inA[4];
+          // one bucket probe at a time, in seed order, until one names a diagonal: an
+          // on-target read costs one L2-missing request here, not two
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            inA[s] = ok[s] && taken < 2;
-            taken += inA[s] ? 1 : 0;
-          }
+            bool have = false;
 #pragma unroll
-          for (int round = 0; round < 2; ++round) {
-            bool go[4];
-            bool any = false;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              go[s] = round == 0 ? inA[s] : (ok[s] && !inA[s]);
-              any = any || go[s];
-            }
-            if (round == 1) {
-              bool have = false;
-#pragma unroll
-              for (int s = 0; s < 4; ++s) have = have || cand[s] != GF_NONE_LIN;
-              if (have) any = false;
-            }
-            if (any) {
-              // at most two seeds go per round: two bucket images in registers
-              int iA = -1, iB = -1;
-              uint32_t kA = 0, kB = 0;
-#pragma unroll
-              for (int s = 0; s < 4; ++s) {
-                if (go[s]) {
-                  if (iA < 0) { iA = s; kA = key[s]; }
-                  else { iB = s; kB = key[s]; }
-                }
-              }
-              uint4 qa[4], qb[4];
-              if (iA >= 0) {  // loads only: no wait inside, so the two probes overlap
-                const uint4* p = (const uint4*)(T.slots + (size_t)gf_bucket_of(kA, T.nbuckets) * GF_SLOTS_PER_BUCKET);
-                qa[0] = p[0]; qa[1] = p[1]; qa[2] = p[2]; qa[3] = p[3];
-              }
-              if (iB >= 0) {
-                const uint4* p = (const uint4*)(T.slots + (size_t)gf_bucket_of(kB, T.nbuckets) * GF_SLOTS_PER_BUCKET);
-                qb[0] = p[0]; qb[1] = p[1]; qb[2] = p[2]; qb[3] = p[3];
-              }
-              uint32_t cA = GF_NONE_LIN, cB = GF_NONE_LIN;
-              if (iA >= 0) {
-                bool ovf;
-                uint32_t val = gf_match_bucket(qa[0], qa[1], qa[2], qa[3], kA, ovf);
-                if (ovf) val = gf_lookup(T, kA);  // rare: the key may live in a later bucket
-                if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) cA = (val & GF_LIN_MASK) - 32u * (uint32_t)iA;
-              }
-              if (iB >= 0) {
-                bool ovf;
-                uint32_t val = gf_match_bucket(qb[0], qb[1], qb[2], qb[3], kB, ovf);
-                if (ovf) val = gf_lookup(T, kB);
-                if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) cB = (val & GF_LIN_MASK) - 32u * (uint32_t)iB;
-              }
-#pragma unroll
-              for (int s = 0; s < 4; ++s) {
-                if (s == iA) cand[s] = cA;
-                if (s == iB) cand[s] = cB;
-              }
+            for (int s2 = 0; s2 < s; ++s2) have = have || cand[s2] != GF_NONE_LIN;
+            if (ok[s] && !have) {
+              const uint32_t val = gf_lookup(T, key[s]);
+              if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) cand[s] = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
             }
           }
         }
 
-#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 4
-        { uint32_t a = nvalid ^ cand[0] ^ cand[1] ^ cand[2] ^ cand[3]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
-#endif
         // verify each distinct candidate diagonal
         int v1 = 0, v2 = 0, nver = 0;
         uint32_t vm[PW];  // verified windows, same sparse layout as cw
