@@ -277,13 +277,13 @@ __global__ __launch_bounds__(256) void gf_k_seedverify(GfTable T, GfStream S, co
             const int wj = 2 * s < PW ? 2 * s : 0;
             key[s] = pk[wj];
             ok[s] = (2 * s < PW) && (cw[wj] & 1u);
-            if (T.bloom_words) {
+            if (T.bloom_in_l2) {
               const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[s] >> 4));  // the window's last 14 bases
               fb[s] = GF_BLOOM_BITS(h2);
               fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // unconditional: always in range
             }
           }
-          if (T.bloom_words) {
+          if (T.bloom_in_l2) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) ok[s] = ok[s] && (fw[s] & fb[s]) == fb[s];
           }

@@ -253,16 +253,27 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
                        ix->d_gdu);
     GF_HIP(hipGetLastError());
   }
-  // presence filter: L2-resident (<= GF_BLOOM_KIB, default 3 MiB), only worth having
-  // when it keeps at least ~2 bits per key
-  uint32_t bloom_words = 0;
+  // presence filter over 14-mers.  Small indexes: <= GF_BLOOM_KIB (default 3 MiB) so that it
+  // lives in every XCD's L2, as long as that leaves >= 2 bits per key.  Larger indexes: about
+  // GF_BLOOM_BIG_BPK (default 4) bits per key, resident in the Infinity Cache instead — a
+  // lookup is then an L2-missing request like a bucket probe, but one lookup answers for two
+  // windows and a negative answer spares both bucket probes.
+  uint32_t bloom_words = 0, bloom_in_l2 = 0;
   {
-    size_t kib = 3072;
+    size_t kib = 3072, big_bpk = 4;
     if (const char* e = getenv("GF_BLOOM_KIB")) kib = (size_t)atol(e);
-    const uint64_t want_words = std::max<uint64_t>(1024, stats[1] / 2);  // 16 bits per key
+    if (const char* e = getenv("GF_BLOOM_BIG_BPK")) big_bpk = (size_t)atol(e);
+    const uint64_t keys = stats[1];
     const uint64_t cap_words = (uint64_t)kib * 1024 / 4;
-    const uint64_t words = std::min(want_words, cap_words);
-    if (kib > 0 && words * 32 >= stats[1] * 2) {
+    uint64_t words = std::min(std::max<uint64_t>(1024, keys / 2), cap_words);  // up to 16 bits per key
+    if (kib > 0 && words * 32 >= keys * 2) {
+      bloom_in_l2 = 1;
+    } else if (kib > 0 && big_bpk > 0) {
+      words = std::min<uint64_t>(keys * big_bpk / 32 + 1024, (64ull << 20) / 4);
+    } else {
+      words = 0;
+    }
+    if (words) {
       bloom_words = (uint32_t)words;
       GF_HIP(hipMalloc((void**)&ix->d_bloom, (size_t)bloom_words * sizeof(uint32_t)));
       GF_HIP(hipMemset(ix->d_bloom, 0, (size_t)bloom_words * sizeof(uint32_t)));
@@ -276,6 +287,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   ix->table.slots = ix->d_slots;
   ix->table.bloom = ix->d_bloom;
   ix->table.bloom_words = bloom_words;
+  ix->table.bloom_in_l2 = bloom_in_l2;
   ix->table.dupes = ix->d_dupes;
   ix->table.lin_base = ix->d_lin_base;
   ix->table.lin_hi = ix->d_lin_hi;
