@@ -219,7 +219,7 @@ def test_with_loaded_ref_constructor(gpu_device, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, "0-nofilter"])
+@pytest.mark.parametrize("variant", [0, 1, 2, "0-nofilter", "0-bigfilter"])
 @pytest.mark.parametrize("shape,scale,n_reads", [("IDX-T", 0.02, 60000), ("IDX-C", 0.004, 60000)])
 def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, variant, monkeypatch):
     """Repeat-rich synthetic genes (2 % repeat family, N bases) and a junction-heavy
@@ -227,8 +227,11 @@ def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, vari
     from genefuserust_amd import Indexer
     from genefuserust_amd import synth
     genes = synth.make_geneset(shape, scale=scale)
-    if variant == "0-nofilter":  # indexes too large for an L2-resident presence filter take this path
+    if variant == "0-nofilter":
         monkeypatch.setenv("GF_BLOOM_KIB", "0")
+        variant = 0
+    elif variant == "0-bigfilter":  # what indexes too large for an L2-resident filter get
+        monkeypatch.setenv("GF_BLOOM_KIB", "1")
         variant = 0
     ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
     ix.make_index()
