@@ -404,6 +404,7 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
       uint32_t m0 = e.todo[0], m1 = e.todo[1], m2 = e.todo[2], m3 = e.todo[3];
       int left = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
       int h = 0;
+      uint32_t pk[PW + 1];
       {
         const uint64_t pos = (uint64_t)((uintptr_t)(bases + offsets[r]) - a0);
         const uint64_t w0 = pos >> 4;
@@ -412,8 +413,11 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
 #pragma unroll
         for (int j = 0; j < PW + 1; ++j) raw[j] = S.pkg[w0 + j];
 #pragma unroll
-        for (int j = 0; j < PW; ++j)
-          s_pk[j * 256 + threadIdx.x] = sh ? ((raw[j] >> sh) | (raw[j + 1] << (32u - sh))) : raw[j];
+        for (int j = 0; j < PW; ++j) {
+          pk[j] = sh ? ((raw[j] >> sh) | (raw[j + 1] << (32u - sh))) : raw[j];
+          s_pk[j * 256 + threadIdx.x] = pk[j];  // phase 2 indexes the words dynamically
+        }
+        pk[PW] = 0;
         s_pk[PW * 256 + threadIdx.x] = 0;
       }
       // A window can only vote if its key is in the table, so count1 <= v1 + (windows that
@@ -423,47 +427,45 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
       uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // windows the filter could not rule out
       bool dead = false;
       if (T.bloom_words) {
-        // windows 2q and 2q+1 share the 14-mer at bases 4q+2 .. 4q+15: one lookup for both
-        uint32_t pr[4] = {(m0 | (m0 >> 1)) & 0x55555555u, (m1 | (m1 >> 1)) & 0x55555555u,
-                          (m2 | (m2 >> 1)) & 0x55555555u, (m3 | (m3 >> 1)) & 0x55555555u};
+        // windows 2q and 2q+1 share the 14-mer at bases 4q+2 .. 4q+15: one lookup for both.
+        // Fully unrolled over the pairs (compile-time shifts on the words in registers),
+        // four look-ups in flight per step.
         const uint32_t td[4] = {m0, m1, m2, m3};
+        uint32_t pp[4] = {0, 0, 0, 0};
         int npos = 0, rem = left;  // not ruled out so far / not asked yet
-        while ((pr[0] | pr[1] | pr[2] | pr[3]) && !dead) {
-          int w[4];  // even window of each pair, -1 = none
-          uint32_t word[4], bits[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (pr[0]) { w[u] = __builtin_ctz(pr[0]); pr[0] &= pr[0] - 1; }
-            else if (pr[1]) { w[u] = 32 + __builtin_ctz(pr[1]); pr[1] &= pr[1] - 1; }
-            else if (pr[2]) { w[u] = 64 + __builtin_ctz(pr[2]); pr[2] &= pr[2] - 1; }
-            else if (pr[3]) { w[u] = 96 + __builtin_ctz(pr[3]); pr[3] &= pr[3] - 1; }
-            else w[u] = -1;
-            const int ww = w[u] < 0 ? 0 : w[u];
-            const int b0 = 2 * ww + 2;  // first base of the shared 14-mer
-            const int j = b0 >> 4;
-            const uint32_t sh = 2u * (uint32_t)(b0 & 15);
-            const uint32_t lo = s_pk[j * 256 + threadIdx.x], hi = s_pk[(j + 1) * 256 + threadIdx.x];
-            const uint32_t s14 = (sh ? ((lo >> sh) | (hi << (32u - sh))) : lo) & 0x0FFFFFFFu;
-            const uint32_t h2 = GF_BLOOM_H2(gf_mix32(s14));
-            bits[u] = GF_BLOOM_BITS(h2);
-            word[u] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // always in range
-          }
+        for (int q0 = 0; q0 < 4 * PW; q0 += 4) {
+          if (!dead) {
+            uint32_t word[4], bits[4], both[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (w[u] >= 0) {
-              const uint32_t both = (td[w[u] >> 5] >> (w[u] & 31)) & 3u;  // which of the pair are to do
-              const int cnt = (int)(both & 1u) + (int)(both >> 1);
+            for (int u = 0; u < 4; ++u) {
+              const int q = q0 + u;
+              const int wbit = (2 * q) & 31, wword = (2 * q) >> 5;
+              both[u] = wword < 4 ? (td[wword] >> wbit) & 3u : 0u;
+              const int b0 = 4 * q + 2;  // first base of the shared 14-mer
+              const int j = b0 >> 4;
+              const uint32_t sh14 = 2u * (uint32_t)(b0 & 15);
+              const uint32_t s14 = ((pk[j] >> sh14) | (pk[j + 1] << (32u - sh14))) & 0x0FFFFFFFu;  // sh14 is never 0
+              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(s14));
+              bits[u] = GF_BLOOM_BITS(h2);
+              word[u] = 0;
+              if (both[u]) word[u] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int q = q0 + u;
+              const int cnt = (int)(both[u] & 1u) + (int)(both[u] >> 1);
               rem -= cnt;
-              if ((word[u] & bits[u]) == bits[u]) {
-                const uint32_t bit = both << (w[u] & 31);
-                if (w[u] < 32) p0 |= bit; else if (w[u] < 64) p1 |= bit; else if (w[u] < 96) p2 |= bit; else p3 |= bit;
+              if (both[u] && (word[u] & bits[u]) == bits[u]) {
+                pp[(2 * q) >> 5 < 4 ? (2 * q) >> 5 : 0] |= both[u] << ((2 * q) & 31);
                 npos += cnt;
               }
             }
+            // even if every window not asked yet could vote, the gate is out of reach
+            dead = (v1 + npos + rem < GF_MAJOR_KEYS / 2) || (v2 + npos + rem < GF_MINOR_KEYS / 2);
           }
-          // even if every window not asked yet could vote, the gate is out of reach
-          dead = (v1 + npos + rem < GF_MAJOR_KEYS / 2) || (v2 + npos + rem < GF_MINOR_KEYS / 2);
         }
+        p0 = pp[0]; p1 = pp[1]; p2 = pp[2]; p3 = pp[3];
       } else {
         p0 = m0; p1 = m1; p2 = m2; p3 = m3;
       }
