@@ -394,7 +394,9 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     // packed stream: covers n * lmax bases from the first read on; reads that lie beyond
     // it (batches with gaps between reads) are routed to the exact kernel
     const uint64_t cap_chunks = ((uint64_t)n * (uint64_t)lmax + 15) / 16 + 8;
-    const int nblk = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 16);
+    int blk_mult = 32;
+    if (const char* e = getenv("GF_NBLK_MULT")) blk_mult = std::max(1, atoi(e));  // experiments
+    const int nblk = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * blk_mult);
     const int64_t per_block = (n + nblk - 1) / nblk;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t sz_pkg = al((cap_chunks + 64) * sizeof(uint32_t));
