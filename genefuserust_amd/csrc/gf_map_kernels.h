@@ -123,14 +123,30 @@ __device__ __forceinline__ int gf_contig_of(const GfTable& T, uint32_t lin) {
   return lo;
 }
 
-// key64 (indexer.rs:698-706) -> site code, GF_NONE_LIN when no vote can carry it
+// the same for a wave-uniform `lin`, without the chain of dependent loads: lin_hi is
+// ascending, so the contig is the number of genes whose interval ends at or below lin;
+// 64 genes per coalesced load, all loads independent
+__device__ __forceinline__ int gf_contig_of_wave(const GfTable& T, uint32_t lin, int lane) {
+  int c = 0;
+  for (int base = 0; base < T.n_genes; base += 64) {
+    const int g = base + lane;
+    const uint32_t hi = g < T.n_genes ? T.lin_hi[g] : 0xFFFFFFFFu;
+    c += __popcll(__ballot(lin >= hi));
+  }
+  return c < T.n_genes ? c : T.n_genes - 1;
+}
+
+// key64 (indexer.rs:698-706) -> site code, GF_NONE_LIN when no vote can carry it.
+// The two table loads are unconditional (clamped index) so that several calls overlap.
 __device__ __forceinline__ uint32_t gf_lin_of_key(const GfTable& T, int64_t key) {
-  int64_t c = key >> 32;
-  if (c < 0 || c >= (int64_t)T.n_genes) return GF_NONE_LIN;
-  int32_t d = (int32_t)(uint32_t)key;
-  int64_t len = (int64_t)T.gene_len[c];
-  if ((int64_t)d >= len || (int64_t)d < -(len + (int64_t)GF_LIN_PAD)) return GF_NONE_LIN;
-  return T.lin_base[c] + (uint32_t)d;
+  const int64_t c = key >> 32;
+  const bool in_range = c >= 0 && c < (int64_t)T.n_genes;
+  const int cc = in_range ? (int)c : 0;
+  const int32_t d = (int32_t)(uint32_t)key;
+  const int64_t len = T.n_genes > 0 ? (int64_t)T.gene_len[cc] : 0;
+  const uint32_t base = T.n_genes > 0 ? T.lin_base[cc] : 0u;
+  const bool ok = in_range && (int64_t)d < len && (int64_t)d >= -(len + (int64_t)GF_LIN_PAD);
+  return ok ? base + (uint32_t)d : GF_NONE_LIN;
 }
 
 // inclusive end of the run starting at s (indexer.rs:644-661)
@@ -406,7 +422,7 @@ __device__ __forceinline__ void gf_finish_read(const GfTable& T, GfMapSmem<LCAP>
         remaining -= c;
         alive = __ballot(mine != GF_NONE_LIN);
         if (c >= GF_MINOR_KEYS / 2) {
-          const int ctg = gf_contig_of(T, K);
+          const int ctg = gf_contig_of_wave(T, K, lane);
           const int32_t d = (int32_t)(K - T.lin_base[ctg]);
           const int64_t key64 = (int64_t)(((uint64_t)(uint32_t)ctg << 32) | (uint64_t)(uint32_t)d);
           if (key64 != 0) {  // indexer.rs:337,342: key 0 never ranks

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
 
 // ---- K_full: the exact wave-per-read kernel over a list of read indices ----
 template <int LCAP, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gf_k_map_reads_list(GfTable T, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(WAVES * 64, 8) void gf_k_map_reads_list(GfTable T, const uint8_t* __restrict__ bases,
                                                                   const int64_t* __restrict__ offsets,
                                                                   const uint32_t* __restrict__ list,
                                                                   const unsigned int* __restrict__ n_list,
