@@ -6,5 +6,6 @@ kernels for gfx950 (csrc/), the C ABI (include/gfmatch.h) and this host-side
 mirror of the reference interface.  See DESIGN.md.
 """
 from .indexer import Fusion, Gene, GenePos, Indexer, SeqMatch, resolve_gene_slice, unpack_matches  # noqa: F401
+from .fusion_mapper import FusionMapper, ReadMatch, edit_distance, reverse_complement  # noqa: F401
 
 __version__ = "0.1.0"

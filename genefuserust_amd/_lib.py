@@ -34,6 +34,15 @@ class GfHit(C.Structure):
     _fields_ = [("read_id", C.c_int64), ("n", C.c_int32), ("pad", C.c_int32), ("m", GfSeqMatch * 2)]
 
 
+class GfReadMatch(C.Structure):
+    _fields_ = [("read_break", C.c_int32), ("gap", C.c_int32), ("left_distance", C.c_int32),
+                ("right_distance", C.c_int32), ("left_position", C.c_int32), ("right_position", C.c_int32),
+                ("left_contig", C.c_int16), ("right_contig", C.c_int16)]
+
+
+GF_RM_NONE, GF_RM_NONE_MAPABLE, GF_RM_MATCH = 0, 1, 2
+
+
 class GfOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("reserved", C.c_int32 * 7)]
 
@@ -106,6 +115,13 @@ def lib() -> C.CDLL:
     L.gf_compact_hits_device.restype = C.c_int
     L.gf_in_required_direction.argtypes = [C.POINTER(GfSeqMatch), i32, vp, i32]
     L.gf_in_required_direction.restype = C.c_int
+    L.gf_fusion_map_read.argtypes = [C.POINTER(C.c_char_p), C.POINTER(i64), i32, vp, C.c_char_p, i64,
+                                     C.POINTER(GfSeqMatch), i32, C.POINTER(GfReadMatch)]
+    L.gf_fusion_map_read.restype = C.c_int
+    L.gf_index_fusion_map_read.argtypes = [vp, vp, C.c_char_p, i64, C.POINTER(GfSeqMatch), i32, C.POINTER(GfReadMatch)]
+    L.gf_index_fusion_map_read.restype = C.c_int
+    L.gf_edit_distance.argtypes = [C.c_char_p, i64, C.c_char_p, i64]
+    L.gf_edit_distance.restype = i64
     L.gf_set_profiling.argtypes = [vp, i32]
     L.gf_set_profiling.restype = C.c_int
     L.gf_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]

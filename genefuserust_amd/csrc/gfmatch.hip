@@ -638,6 +638,143 @@ int gf_in_required_direction(const gf_seqmatch* m, int32_t n, const uint8_t* gen
   return 0;
 }
 
+// ---- FusionMapper::map_read tail, host logic --------------------
+
+namespace {
+
+// Hyyro's block-based bit-vector Levenshtein (the algorithm of edit_distance.rs:12-92):
+// `a` is the pattern (blocks of 64 symbols), `b` the text.
+size_t ed_bitparallel(const unsigned char* a, size_t asize, const unsigned char* b, size_t bsize) {
+  const size_t tmax = (asize - 1) >> 6;      // index of the last block
+  const size_t tlen = asize - tmax * 64;     // symbols in the last block
+  const size_t nb = tmax + 1;
+  std::vector<uint64_t> peq(256 * nb, 0);    // match masks per symbol and block
+  for (size_t i = 0; i < asize; ++i) peq[(size_t)a[i] * nb + (i >> 6)] |= 1ull << (i & 63);
+  std::vector<uint64_t> vp(nb, ~0ull), vn(nb, 0), hp(nb, 0), hn(nb, 0);
+  vp[tmax] = tlen == 64 ? ~0ull : ((1ull << tlen) - 1);
+  const uint64_t top = 1ull << (tlen - 1), msb = 1ull << 63;
+  size_t d = asize;
+  for (size_t i = 0; i < bsize; ++i) {
+    const uint64_t* pm = &peq[(size_t)b[i] * nb];
+    for (size_t r = 0; r < nb; ++r) {
+      uint64_t x = pm[r];
+      const bool carry_n = r > 0 && (hn[r - 1] & msb);
+      if (carry_n) x |= 1ull;
+      const uint64_t d0 = (((x & vp[r]) + vp[r]) ^ vp[r]) | x | vn[r];
+      hp[r] = vn[r] | ~(d0 | vp[r]);
+      hn[r] = d0 & vp[r];
+      uint64_t y = hp[r] << 1;
+      if (r == 0 || (hp[r - 1] & msb)) y |= 1ull;
+      vp[r] = (hn[r] << 1) | ~(d0 | y);
+      if (carry_n) vp[r] |= 1ull;
+      vn[r] = d0 & y;
+    }
+    if (hp[tmax] & top) d += 1;
+    else if (hn[tmax] & top) d -= 1;
+  }
+  return d;
+}
+
+size_t ed_dp(const unsigned char* a, size_t n1, const unsigned char* b, size_t n2) {
+  std::vector<uint32_t> prev(n2 + 1), cur(n2 + 1);
+  for (size_t j = 0; j <= n2; ++j) prev[j] = (uint32_t)j;
+  for (size_t i = 1; i <= n1; ++i) {
+    cur[0] = (uint32_t)i;
+    for (size_t j = 1; j <= n2; ++j)
+      cur[j] = std::min(std::min(prev[j], cur[j - 1]) + 1, prev[j - 1] + (a[i - 1] == b[j - 1] ? 0u : 1u));
+    std::swap(prev, cur);
+  }
+  return prev[n2];
+}
+
+// edit_distance.rs:159-193: the longer string is the pattern unless it needs more than 10 blocks
+size_t host_edit_distance(const unsigned char* a, size_t asize, const unsigned char* b, size_t bsize) {
+  if (asize == 0) return bsize;
+  if (bsize == 0) return asize;
+  if (asize < bsize) { std::swap(a, b); std::swap(asize, bsize); }
+  if (((asize - 1) >> 6) + 1 > 10) { std::swap(a, b); std::swap(asize, bsize); }
+  if (((asize - 1) >> 6) + 1 <= 10) return ed_bitparallel(a, asize, b, bsize);
+  return ed_dp(a, asize, b, bsize);
+}
+
+char host_complement(char c) {  // sequence.rs:51-59
+  switch (c) {
+    case 'A': case 'a': return 'T';
+    case 'T': case 't': return 'A';
+    case 'C': case 'c': return 'G';
+    case 'G': case 'g': return 'C';
+    default: return 'N';
+  }
+}
+
+// fusion_mapper.rs:225-251
+int32_t host_calc_ed(const char* fs, int64_t fs_len, const char* seq, int32_t seq_len, int32_t start, int32_t end) {
+  if ((start >= 0 && end <= 0) || (start <= 0 && end >= 0)) return -1;  // not on one strand
+  if (std::abs((int64_t)start) >= fs_len || std::abs((int64_t)end) >= fs_len) return -2;
+  std::string ss(seq, (size_t)seq_len);
+  if (start < 0) {
+    std::string rc((size_t)seq_len, 'N');
+    for (int32_t i = 0; i < seq_len; ++i) rc[(size_t)(seq_len - 1 - i)] = host_complement(seq[i]);
+    ss.swap(rc);
+    const int32_t tmp = start;
+    start = -end;
+    end = -tmp;
+  }
+  return (int32_t)host_edit_distance((const unsigned char*)ss.data(), ss.size(), (const unsigned char*)fs + start,
+                                     (size_t)(end - start + 1));
+}
+
+}  // namespace
+
+int64_t gf_edit_distance(const char* a, int64_t alen, const char* b, int64_t blen) {
+  if (alen < 0 || blen < 0 || (alen > 0 && !a) || (blen > 0 && !b)) return fail(GF_ERR_ARG, "bad argument");
+  return (int64_t)host_edit_distance((const unsigned char*)a, (size_t)alen, (const unsigned char*)b, (size_t)blen);
+}
+
+int gf_fusion_map_read(const char* const* fusion_seqs, const int64_t* fusion_lens, int32_t n_genes,
+                       const uint8_t* gene_reversed, const char* seq, int64_t len, const gf_seqmatch* mapping,
+                       int32_t n_mapping, gf_readmatch* out) {
+  if (n_mapping < 0 || len < 0 || (n_mapping > 0 && !mapping)) return fail(GF_ERR_ARG, "bad argument");
+  if (n_mapping < 2) return GF_RM_NONE;  // fusion_mapper.rs:107-115
+  const int dir = gf_in_required_direction(mapping, n_mapping, gene_reversed, n_genes);
+  if (dir < 0) return dir;
+  if (!dir) return GF_RM_NONE_MAPABLE;   // :118-123
+  if (n_mapping != 2) return GF_RM_NONE_MAPABLE;  // make_match returns None (:155-157)
+  if (!out || !seq || !fusion_seqs || !fusion_lens) return fail(GF_ERR_ARG, "null argument");
+  gf_seqmatch left = mapping[0], right = mapping[1];
+  if (left.seq_start > right.seq_start) std::swap(left, right);
+  if (left.contig < 0 || left.contig >= n_genes || right.contig < 0 || right.contig >= n_genes)
+    return fail(GF_ERR_ARG, "contig out of range");
+  const int32_t read_break = (left.seq_end + right.seq_start) / 2;  // :173
+  left.position += read_break;                                       // :177-178
+  right.position += read_break + 1;
+  const int32_t left_len = read_break + 1, right_len = (int32_t)len - (read_break + 1);  // :199-201
+  if (left_len < 0 || right_len < 0 || left_len > len) return fail(GF_ERR_ARG, "segments outside the read");
+  out->read_break = read_break;
+  out->gap = right.seq_start - left.seq_end - 1;                     // :180
+  out->left_contig = left.contig;
+  out->left_position = left.position;
+  out->right_contig = right.contig;
+  out->right_position = right.position;
+  out->left_distance = host_calc_ed(fusion_seqs[left.contig], fusion_lens[left.contig], seq, left_len,
+                                    left.position - left_len + 1, left.position);
+  out->right_distance = host_calc_ed(fusion_seqs[right.contig], fusion_lens[right.contig], seq + read_break + 1,
+                                     right_len, right.position, right.position + right_len - 1);
+  return GF_RM_MATCH;
+}
+
+int gf_index_fusion_map_read(const gf_index* idx, const uint8_t* gene_reversed, const char* seq, int64_t len,
+                             const gf_seqmatch* mapping, int32_t n_mapping, gf_readmatch* out) {
+  if (!idx) return fail(GF_ERR_ARG, "null index");
+  std::vector<const char*> p(idx->fusion_seq.size());
+  std::vector<int64_t> l(idx->fusion_seq.size());
+  for (size_t c = 0; c < p.size(); ++c) {
+    p[c] = idx->fusion_seq[c].data();
+    l[c] = (int64_t)idx->fusion_seq[c].size();
+  }
+  return gf_fusion_map_read(p.data(), l.data(), (int32_t)p.size(), gene_reversed, seq, len, mapping, n_mapping, out);
+}
+
 int gf_set_map_variant(gf_index* idx, int32_t variant) {
   if (!idx || variant < 0 || variant > 2) return fail(GF_ERR_ARG, "bad variant");
   idx->map_variant = variant;

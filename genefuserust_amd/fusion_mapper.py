@@ -1,0 +1,99 @@
+"""Host-side mirror of the part of ``FusionMapper`` that sits directly on the hot path
+(src/core/fusion_mapper.rs:93-251): ``map_read`` = Indexer.map_read,
+the ``mapable`` rule, the direction gate, ``make_match`` and ``calc_distance``.
+
+Same names and behaviour as the Rust type; the batch forms put every read through one
+GPU call (``Indexer.map_reads_packed``) and only the reads that come back with two
+segments (about 0.1 %) through the host logic, like the reference keeps that logic on
+the CPU.  ``scan_single_end`` adds the reverse-complement retry of the scanners
+(sescanner.rs:188-195, pescanner.rs:458-513).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import GF_RM_MATCH, GF_RM_NONE, GfReadMatch, GfSeqMatch
+from .indexer import BytesLike, GenePos, Indexer, SeqMatch, _as_bytes
+
+_COMP = bytes.maketrans(b"ACGTacgt", b"TGCATGCA")
+
+
+def reverse_complement(seq: bytes) -> bytes:
+    """sequence.rs:22-60: anything outside ACGTacgt becomes N, output upper case."""
+    clean = bytes(c if c in b"ACGTacgt" else 78 for c in seq)
+    return clean.translate(_COMP)[::-1]
+
+
+@dataclass
+class ReadMatch:
+    """The fields of src/core/read_match.rs:18-30 that make_match / calc_distance set."""
+    m_read: bytes
+    m_read_break: int
+    m_left_gp: GenePos
+    m_right_gp: GenePos
+    m_gap: int
+    m_left_distance: int
+    m_right_distance: int
+    m_reversed: bool = False
+
+
+def edit_distance(a: BytesLike, b: BytesLike) -> int:
+    a, b = _as_bytes(a), _as_bytes(b)
+    return int(_lib.check(_lib.lib().gf_edit_distance(a, len(a), b, len(b))))
+
+
+class FusionMapper:
+    def __init__(self, indexer: Indexer):
+        self.m_indexer = indexer
+        self._rev = np.array([f.is_reversed() for f in indexer.m_fusions] or [0], dtype=np.uint8)
+
+    def _tail(self, seq: bytes, mapping: Sequence[SeqMatch]) -> Tuple[Optional[ReadMatch], bool]:
+        n = len(mapping)
+        arr = (GfSeqMatch * max(n, 1))()
+        for k, m in enumerate(mapping):
+            arr[k] = GfSeqMatch(m.seq_start, m.seq_end, m.start_gp.position, m.start_gp.contig, 0)
+        out = GfReadMatch()
+        st = _lib.check(_lib.lib().gf_index_fusion_map_read(self.m_indexer._handle(), self._rev.ctypes.data, seq,
+                                                            len(seq), arr, n, C.byref(out)))
+        if st != GF_RM_MATCH:
+            return None, st != GF_RM_NONE
+        return ReadMatch(seq, out.read_break, GenePos(out.left_contig, out.left_position),
+                         GenePos(out.right_contig, out.right_position), out.gap, out.left_distance,
+                         out.right_distance), True
+
+    def map_read(self, r: BytesLike) -> Tuple[Optional[ReadMatch], bool]:
+        """FusionMapper::map_read: returns (match or None, mapable)."""
+        seq = _as_bytes(r)
+        return self._tail(seq, self.m_indexer.map_read(seq))
+
+    def map_reads(self, reads: Sequence[BytesLike]) -> List[Tuple[Optional[ReadMatch], bool]]:
+        from .synth import ragged_batch
+        seqs = [_as_bytes(r) for r in reads]
+        bases, offsets = ragged_batch(seqs)
+        counts, matches = self.m_indexer.map_reads_packed(bases, offsets)
+        out: List[Tuple[Optional[ReadMatch], bool]] = [(None, False)] * len(seqs)
+        for r in np.nonzero(counts >= 2)[0]:
+            mp = [SeqMatch(int(matches[r, k]["seq_start"]), int(matches[r, k]["seq_end"]),
+                           GenePos(int(matches[r, k]["contig"]), int(matches[r, k]["position"])))
+                  for k in range(int(counts[r]))]
+            out[int(r)] = self._tail(seqs[int(r)], mp)
+        return out
+
+    def scan_single_end(self, reads: Sequence[BytesLike]) -> List[Optional[ReadMatch]]:
+        """sescanner.rs:188-195: map the read; when it is mapable but gives no match, map its
+        reverse complement (set_reversed(true) on that match).  Two GPU calls per batch."""
+        first = self.map_reads(reads)
+        result: List[Optional[ReadMatch]] = [m for m, _ in first]
+        retry = [i for i, (m, mapable) in enumerate(first) if m is None and mapable]
+        if retry:
+            second = self.map_reads([reverse_complement(_as_bytes(reads[i])) for i in retry])
+            for i, (m, _) in zip(retry, second):
+                if m is not None:
+                    m.m_reversed = True
+                    result[i] = m
+        return result

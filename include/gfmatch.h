@@ -154,6 +154,44 @@ int gf_compact_hits_device(const gf_index* idx, const void* d_counts, const void
 int gf_in_required_direction(const gf_seqmatch* matches, int32_t n, const uint8_t* gene_reversed,
                              int32_t n_genes);
 
+/* --- the immediate caller, host logic ---------------------
+ * gf_fusion_map_read is FusionMapper::map_read after its call of Indexer::map_read
+ * (fusion_mapper.rs:100-131): `mapping` is the Vec<SeqMatch> of the read.  Returns
+ *   GF_RM_NONE          None, *mapable = false   (fewer than 2 segments, :107-115)
+ *   GF_RM_NONE_MAPABLE  None, *mapable = true    (wrong direction, :118-123: the caller
+ *                                                 retries the reverse complement,
+ *                                                 pescanner.rs:458-468, sescanner.rs:188-195)
+ *   GF_RM_MATCH         Some(ReadMatch) written to *out: make_match (:154-194) and
+ *                       calc_distance / calc_ed (:196-251) with edit_distance
+ *                       (edit_distance.rs:12-197; -1 = ends on different strands, -2 = off the gene)
+ * or a negative error.  fusion_seqs/fusion_lens = Indexer.m_fusion_seq (upper-cased gene
+ * slices), gene_reversed[c] = Fusion::is_reversed().  Runs on the ~0.1 % of reads that
+ * return two segments; stays on the host like the reference's. */
+#define GF_RM_NONE 0
+#define GF_RM_NONE_MAPABLE 1
+#define GF_RM_MATCH 2
+
+typedef struct gf_readmatch {
+  int32_t read_break;     /* ReadMatch.m_read_break */
+  int32_t gap;            /* m_gap */
+  int32_t left_distance;  /* m_left_distance */
+  int32_t right_distance; /* m_right_distance */
+  int32_t left_position;  /* m_left_gp.position */
+  int32_t right_position; /* m_right_gp.position */
+  int16_t left_contig;    /* m_left_gp.contig */
+  int16_t right_contig;   /* m_right_gp.contig */
+} gf_readmatch;
+
+int gf_fusion_map_read(const char* const* fusion_seqs, const int64_t* fusion_lens, int32_t n_genes,
+                       const uint8_t* gene_reversed, const char* seq, int64_t len,
+                       const gf_seqmatch* mapping, int32_t n_mapping, gf_readmatch* out);
+/* the same with the fusion sequences of an index */
+int gf_index_fusion_map_read(const gf_index* idx, const uint8_t* gene_reversed, const char* seq, int64_t len,
+                             const gf_seqmatch* mapping, int32_t n_mapping, gf_readmatch* out);
+/* edit_distance (edit_distance.rs:159-193): Levenshtein distance, bit-parallel up to
+ * 640 symbols of the longer string, dynamic programming beyond */
+int64_t gf_edit_distance(const char* a, int64_t alen, const char* b, int64_t blen);
+
 /* --- instrumentation -------------------------------------------------------
  * With profiling on, gf_map_reads_device brackets its mapping kernel with HIP
  * events on the launch stream; gf_last_map_kernel_ms synchronises on them and

@@ -186,3 +186,47 @@ def in_required_direction(m: Sequence[Match], reversed_flags: Sequence[bool]) ->
     if not lrev and rrev:
         return True
     return left[2] < right[2]
+
+
+# ---- FusionMapper::map_read tail, written from the prose of Appendix A.4
+# and fusion_mapper.rs:196-251; the edit distance is the textbook Levenshtein DP on purpose
+# (the reference's bit-parallel routine must equal it).
+
+def levenshtein(a: str, b: str) -> int:
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def calc_ed(fusion_seq: Sequence[str], seq: str, contig: int, start: int, end: int) -> int:
+    if (start >= 0 and end <= 0) or (start <= 0 and end >= 0):
+        return -1
+    fs = fusion_seq[contig]
+    if abs(start) >= len(fs) or abs(end) >= len(fs):
+        return -2
+    if start < 0:
+        seq = revcomp(seq)
+        start, end = -end, -start
+    return levenshtein(seq, fs[start:end + 1])
+
+
+def fusion_map_read(fusion_seq: Sequence[str], reversed_flags: Sequence[bool], read: str, mapping: Sequence[Match]):
+    """(status, fields): 0 = None/unmapable, 1 = None/mapable, 2 = match."""
+    if len(mapping) < 2:
+        return 0, None
+    if not in_required_direction(mapping, reversed_flags):
+        return 1, None
+    left, right = sorted(mapping[:2], key=lambda m: m[0]) if mapping[0][0] != mapping[1][0] else (mapping[0], mapping[1])
+    brk = (left[1] + right[0]) // 2 if (left[1] + right[0]) >= 0 else -((-(left[1] + right[0])) // 2)
+    lpos, rpos = left[3] + brk, right[3] + brk + 1
+    left_len, right_len = brk + 1, len(read) - (brk + 1)
+    return 2, {
+        "read_break": brk, "gap": right[0] - left[1] - 1,
+        "left_contig": left[2], "left_position": lpos, "right_contig": right[2], "right_position": rpos,
+        "left_distance": calc_ed(fusion_seq, read[:left_len], left[2], lpos - left_len + 1, lpos),
+        "right_distance": calc_ed(fusion_seq, read[brk + 1:], right[2], rpos, rpos + right_len - 1),
+    }

@@ -488,3 +488,147 @@ int32_t orc_in_required_direction(const orc_seqmatch* m, int32_t n, const uint8_
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// the immediate caller, FusionMapper::map_read + make_match +
+// calc_distance + calc_ed (src/core/fusion_mapper.rs:93-251) and edit_distance
+// (src/core/edit_distance.rs:12-197), restated literally.  Test infrastructure only.
+// ---------------------------------------------------------------------------
+namespace {
+
+// src/core/edit_distance.rs:12-92 (Hyyro/Myers bit-parallel, N 64-bit blocks)
+size_t edit_distance_bpv(std::map<char, std::vector<uint64_t>>& cmap, const std::string& v, size_t vsize,
+                         size_t tmax, size_t tlen, size_t N) {
+  size_t d = tmax * 64 + tlen;
+  const uint64_t top = 1ull << ((tlen - 1) & 63);
+  const uint64_t lmb = 1ull << 63;
+  std::vector<uint64_t> d0(N, 0), hp(N, 0), hn(N, 0), vp(tmax + 1, 0), vn(tmax + 1, 0);
+  for (size_t i = 0; i < tmax; ++i) vp[i] = ~0ull;
+  for (size_t i = 0; i < tlen; ++i) vp[tmax] |= 1ull << (i & 63);
+  for (size_t i = 0; i < vsize; ++i) {
+    auto it = cmap.find(v[i]);
+    if (it == cmap.end()) it = cmap.emplace(v[i], std::vector<uint64_t>(N, 0)).first;
+    const std::vector<uint64_t>& pm = it->second;
+    for (size_t r = 0; r <= tmax; ++r) {
+      uint64_t x = pm[r];
+      if (r > 0 && (hn[r - 1] & lmb) != 0) x |= 1ull;
+      d0[r] = (((x & vp[r]) + vp[r]) ^ vp[r]) | x | vn[r];
+      hp[r] = vn[r] | ~(d0[r] | vp[r]);
+      hn[r] = d0[r] & vp[r];
+      x = hp[r] << 1;
+      if (r == 0 || (hp[r - 1] & lmb) != 0) x |= 1ull;
+      vp[r] = (hn[r] << 1) | ~(d0[r] | x);
+      if (r > 0 && (hn[r - 1] & lmb) != 0) vp[r] |= 1;
+      vn[r] = d0[r] & x;
+    }
+    if ((hp[tmax] & top) != 0) d += 1;
+    else if ((hn[tmax] & top) != 0) d -= 1;
+  }
+  return d;
+}
+
+// src/core/edit_distance.rs:94-120
+size_t edit_distance_dp(const std::string& s1, size_t n1, const std::string& s2, size_t n2) {
+  std::vector<std::vector<uint32_t>> d(n1 + 1, std::vector<uint32_t>(n2 + 1, 0));
+  for (size_t i = 0; i <= n1; ++i) d[i][0] = (uint32_t)i;
+  for (size_t j = 0; j <= n2; ++j) d[0][j] = (uint32_t)j;
+  for (size_t i = 1; i <= n1; ++i)
+    for (size_t j = 1; j <= n2; ++j)
+      d[i][j] = std::min(std::min(d[i - 1][j], d[i][j - 1]) + 1, d[i - 1][j - 1] + (s1[i - 1] == s2[j - 1] ? 0u : 1u));
+  return d[n1][n2];
+}
+
+// src/core/edit_distance.rs:122-157
+size_t edit_distance_map(const std::string& a, size_t asize, const std::string& b, size_t bsize, size_t N) {
+  std::map<char, std::vector<uint64_t>> cmap;
+  const size_t tmax = (asize - 1) >> 6;
+  const size_t tlen = asize - tmax * 64;
+  for (size_t i = 0; i < tmax; ++i)
+    for (size_t j = 0; j < 64; ++j) {
+      auto it = cmap.emplace(a[i * 64 + j], std::vector<uint64_t>(N, 0)).first;
+      it->second[i] |= 1ull << j;
+    }
+  for (size_t i = 0; i < tlen; ++i) {
+    auto it = cmap.emplace(a[tmax * 64 + i], std::vector<uint64_t>(N, 0)).first;
+    it->second[tmax] |= 1ull << i;
+  }
+  return edit_distance_bpv(cmap, b, bsize, tmax, tlen, N);
+}
+
+// src/core/edit_distance.rs:159-193
+size_t edit_distance(std::string a, size_t asize, std::string b, size_t bsize) {
+  if (asize == 0) return bsize;
+  if (bsize == 0) return asize;
+  if (asize < bsize) { std::swap(a, b); std::swap(asize, bsize); }
+  size_t vsize = ((asize - 1) >> 6) + 1;
+  if (vsize > 10) {
+    std::swap(a, b);
+    std::swap(asize, bsize);
+    vsize = ((asize - 1) >> 6) + 1;
+  }
+  if (vsize >= 1 && vsize <= 10) return edit_distance_map(a, asize, b, bsize, vsize);
+  return edit_distance_dp(a, asize, b, bsize);
+}
+
+// src/core/fusion_mapper.rs:225-251
+int32_t calc_ed(const std::vector<std::string>& fusion_seq, const std::string& seq, int32_t contig, int32_t start,
+                int32_t end) {
+  if ((start >= 0 && end <= 0) || (start <= 0 && end >= 0)) return -1;
+  const std::string& fs = fusion_seq.at((size_t)contig);
+  if (std::abs(start) >= (int32_t)fs.size() || std::abs(end) >= (int32_t)fs.size()) return -2;
+  std::string ss = seq;
+  if (start < 0) {
+    ss = reverse_complement(seq);
+    int32_t tmp = start;
+    start = -end;
+    end = -tmp;
+  }
+  std::string ref_str = fs.substr((size_t)start, (size_t)(end - start + 1));
+  return (int32_t)edit_distance(ss, ss.size(), ref_str, ref_str.size());
+}
+
+}  // namespace
+
+extern "C" {
+
+struct orc_readmatch {
+  int32_t read_break, gap, left_distance, right_distance;
+  int32_t left_position, right_position;
+  int16_t left_contig, right_contig;
+};
+
+int64_t orc_edit_distance(const char* a, int64_t alen, const char* b, int64_t blen) {
+  return (int64_t)edit_distance(std::string(a, (size_t)alen), (size_t)alen, std::string(b, (size_t)blen), (size_t)blen);
+}
+
+// FusionMapper::map_read after m_indexer.map_read (fusion_mapper.rs:100-131):
+// returns 0 = None with mapable=false, 1 = None with mapable=true, 2 = Some(ReadMatch).
+int32_t orc_fusion_map_read(void* h, const uint8_t* reversed, const char* seq, int64_t len,
+                            const orc_seqmatch* mapping, int32_t n_mapping, orc_readmatch* out) {
+  Indexer* ix = (Indexer*)h;
+  if (n_mapping < 2) return 0;                                         // :107-115
+  if (!orc_in_required_direction(mapping, n_mapping, reversed)) return 1;  // :118-123
+  if (n_mapping != 2) return 1;                                        // make_match :155-157 (None, mapable stays true)
+  orc_seqmatch left = mapping[0], right = mapping[1];                  // :160-166
+  if (left.seq_start > right.seq_start) std::swap(left, right);
+  const int32_t read_break = (left.seq_end + right.seq_start) / 2;     // :173
+  left.position += read_break;                                         // :177-178
+  right.position += read_break + 1;
+  const int32_t gap = right.seq_start - left.seq_end - 1;              // :180
+  const std::string s(seq, (size_t)len);
+  const int32_t left_len = read_break + 1;                             // calc_distance :199-221
+  const int32_t right_len = (int32_t)len - (read_break + 1);
+  const std::string left_seq = s.substr(0, (size_t)left_len);
+  const std::string right_seq = s.substr((size_t)(read_break + 1), (size_t)right_len);
+  out->read_break = read_break;
+  out->gap = gap;
+  out->left_contig = left.contig;
+  out->left_position = left.position;
+  out->right_contig = right.contig;
+  out->right_position = right.position;
+  out->left_distance = calc_ed(ix->m_fusion_seq, left_seq, left.contig, left.position - left_len + 1, left.position);
+  out->right_distance = calc_ed(ix->m_fusion_seq, right_seq, right.contig, right.position, right.position + right_len - 1);
+  return 2;
+}
+
+}  // extern "C"

@@ -60,6 +60,10 @@ def lib() -> C.CDLL:
     L.orc_reverse_complement.argtypes = [C.c_char_p, i64, C.c_char_p]
     L.orc_in_required_direction.argtypes = [vp, i32, vp]
     L.orc_in_required_direction.restype = i32
+    L.orc_edit_distance.argtypes = [C.c_char_p, i64, C.c_char_p, i64]
+    L.orc_edit_distance.restype = i64
+    L.orc_fusion_map_read.argtypes = [vp, vp, C.c_char_p, i64, vp, i32, vp]
+    L.orc_fusion_map_read.restype = i32
     _lib = L
     return L
 
@@ -165,3 +169,25 @@ def in_required_direction(matches: Sequence[Match], reversed_flags: Sequence[boo
         arr[k] = (m[0], m[1], m[3], m[2], 0)
     rev = np.asarray(list(reversed_flags) or [0], dtype=np.uint8)
     return bool(lib().orc_in_required_direction(arr.ctypes.data, len(matches), rev.ctypes.data))
+
+
+ORC_READMATCH = np.dtype([("read_break", "<i4"), ("gap", "<i4"), ("left_distance", "<i4"), ("right_distance", "<i4"),
+                          ("left_position", "<i4"), ("right_position", "<i4"), ("left_contig", "<i2"),
+                          ("right_contig", "<i2")])
+
+
+def edit_distance(a: bytes, b: bytes) -> int:
+    return int(lib().orc_edit_distance(a, len(a), b, len(b)))
+
+
+def fusion_map_read(ox: "OracleIndexer", reversed_flags: Sequence[bool], seq: bytes, mapping: Sequence[Match]):
+    """FusionMapper::map_read after Indexer::map_read: (status, readmatch dict or None);
+    status 0 = None/unmapable, 1 = None/mapable, 2 = match."""
+    arr = np.zeros(max(len(mapping), 1), dtype=ORC_SEQMATCH)
+    for k, m in enumerate(mapping):
+        arr[k] = (m[0], m[1], m[3], m[2], 0)
+    rev = np.asarray(list(reversed_flags) or [0], dtype=np.uint8)
+    out = np.zeros(1, dtype=ORC_READMATCH)
+    st = int(lib().orc_fusion_map_read(ox._h, rev.ctypes.data, seq, len(seq), arr.ctypes.data, len(mapping),
+                                       out.ctypes.data))
+    return st, ({k: int(out[0][k]) for k in ORC_READMATCH.names} if st == 2 else None)
