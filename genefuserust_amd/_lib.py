@@ -120,6 +120,11 @@ def lib() -> C.CDLL:
     L.gf_fusion_map_read.restype = C.c_int
     L.gf_index_fusion_map_read.argtypes = [vp, vp, C.c_char_p, i64, C.POINTER(GfSeqMatch), i32, C.POINTER(GfReadMatch)]
     L.gf_index_fusion_map_read.restype = C.c_int
+    L.gf_fast_merge_device.argtypes = [vp] * 7 + [i64] + [vp] * 6
+    L.gf_fast_merge_device.restype = C.c_int
+    L.gf_fast_merge.argtypes = [vp, C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p,
+                                C.POINTER(i32), C.POINTER(i32)]
+    L.gf_fast_merge.restype = C.c_int
     L.gf_edit_distance.argtypes = [C.c_char_p, i64, C.c_char_p, i64]
     L.gf_edit_distance.restype = i64
     L.gf_set_profiling.argtypes = [vp, i32]

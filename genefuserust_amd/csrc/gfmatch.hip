@@ -19,6 +19,7 @@
 #include "gf_compact_kernels.h"
 #include "gf_index_kernels.h"
 #include "gf_map_kernels.h"
+#include "gf_merge_kernels.h"
 #include "gf_pipe_kernels.h"
 #include "gf_table.h"
 
@@ -773,6 +774,56 @@ int gf_index_fusion_map_read(const gf_index* idx, const uint8_t* gene_reversed, 
     l[c] = (int64_t)idx->fusion_seq[c].size();
   }
   return gf_fusion_map_read(p.data(), l.data(), (int32_t)p.size(), gene_reversed, seq, len, mapping, n_mapping, out);
+}
+
+// ---- SequenceReadPair::fast_merge on the device ----
+int gf_fast_merge_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
+                         const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets, int64_t n,
+                         const void* d_out_pos, void* d_out_bases, void* d_out_quals, void* d_out_len,
+                         void* d_out_diff, void* stream) {
+  if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
+  if (n == 0) return GF_OK;
+  if (!d_l_offsets || !d_r_offsets || !d_out_len || !d_out_diff) return fail(GF_ERR_ARG, "null device pointer");
+  if (d_out_bases && (!d_out_pos || !d_out_quals)) return fail(GF_ERR_ARG, "out_bases without out_pos/out_quals");
+  DeviceGuard guard(idx->device);
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 32);
+  hipLaunchKernelGGL(gf_k_fast_merge, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_l_bases,
+                     (const uint8_t*)d_l_quals, (const int64_t*)d_l_offsets, (const uint8_t*)d_r_bases,
+                     (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int64_t*)d_out_pos,
+                     (uint8_t*)d_out_bases, (uint8_t*)d_out_quals, (int32_t*)d_out_len, (int32_t*)d_out_diff);
+  GF_HIP(hipGetLastError());
+  return GF_OK;
+}
+
+int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, int32_t len1, const char* r_seq,
+                  const char* r_qual, int32_t len2, char* out_seq, char* out_qual, int32_t* out_len,
+                  int32_t* out_diff) {
+  if (!idx || len1 < 0 || len2 < 0 || !out_seq || !out_qual || !out_len || !out_diff)
+    return fail(GF_ERR_ARG, "bad argument");
+  DeviceGuard guard(idx->device);
+  DevBuf<uint8_t> dl, dlq, dr, drq, dob, doq;
+  DevBuf<int64_t> dlo, dro, dpos;
+  DevBuf<int32_t> dlen, ddiff;
+  GF_HIP(dl.alloc((size_t)len1 + 1)); GF_HIP(dlq.alloc((size_t)len1 + 1));
+  GF_HIP(dr.alloc((size_t)len2 + 1)); GF_HIP(drq.alloc((size_t)len2 + 1));
+  GF_HIP(dob.alloc((size_t)len1 + len2 + 1)); GF_HIP(doq.alloc((size_t)len1 + len2 + 1));
+  GF_HIP(dlo.alloc(2)); GF_HIP(dro.alloc(2)); GF_HIP(dpos.alloc(1)); GF_HIP(dlen.alloc(1)); GF_HIP(ddiff.alloc(1));
+  const int64_t lo[2] = {0, len1}, ro[2] = {0, len2}, pos0 = 0;
+  if (len1) { GF_HIP(hipMemcpy(dl.p, l_seq, (size_t)len1, hipMemcpyHostToDevice)); GF_HIP(hipMemcpy(dlq.p, l_qual, (size_t)len1, hipMemcpyHostToDevice)); }
+  if (len2) { GF_HIP(hipMemcpy(dr.p, r_seq, (size_t)len2, hipMemcpyHostToDevice)); GF_HIP(hipMemcpy(drq.p, r_qual, (size_t)len2, hipMemcpyHostToDevice)); }
+  GF_HIP(hipMemcpy(dlo.p, lo, sizeof lo, hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(dro.p, ro, sizeof ro, hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(dpos.p, &pos0, sizeof pos0, hipMemcpyHostToDevice));
+  int rc = gf_fast_merge_device(idx, dl.p, dlq.p, dlo.p, dr.p, drq.p, dro.p, 1, dpos.p, dob.p, doq.p, dlen.p, ddiff.p,
+                                nullptr);
+  if (rc != GF_OK) return rc;
+  GF_HIP(hipDeviceSynchronize());
+  GF_HIP(hipMemcpy(out_len, dlen.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+  GF_HIP(hipMemcpy(out_diff, ddiff.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (*out_len <= 0) return 0;
+  GF_HIP(hipMemcpy(out_seq, dob.p, (size_t)*out_len, hipMemcpyDeviceToHost));
+  GF_HIP(hipMemcpy(out_qual, doq.p, (size_t)*out_len, hipMemcpyDeviceToHost));
+  return 1;
 }
 
 int gf_set_map_variant(gf_index* idx, int32_t variant) {

@@ -1,0 +1,138 @@
+"""SURVEY.md §8(f)-2 — the step before the hot path: ``SequenceReadPair::fast_merge``
+(src/core/read.rs:313-440) on the device, and the pair policy of
+``PairEndScanner::scan_pair_end`` (src/core/pescanner.rs:427-518) over a whole batch.
+
+Device work is ``gf_fast_merge_device`` (csrc/gf_merge_kernels.h) behind the C ABI; torch is
+used for device buffers and one prefix sum only.  No CPU fallback: without the HIP library
+and a GPU every call here raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, NamedTuple, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .fusion_mapper import FusionMapper, ReadMatch, reverse_complement
+from .indexer import BytesLike, Indexer, _as_bytes
+
+
+class MergedRead(NamedTuple):
+    """The SequenceRead fast_merge returns: name suffix " merged_diff_{diff}" (read.rs:372)."""
+    seq: bytes
+    quality: bytes
+    diff: int
+
+
+class SequenceReadPair:
+    """read.rs:300-311.  ``left``/``right`` are (seq, quality) as read from the FASTQ files."""
+
+    def __init__(self, left: Tuple[BytesLike, BytesLike], right: Tuple[BytesLike, BytesLike]):
+        self.m_left = (_as_bytes(left[0]), _as_bytes(left[1]))
+        self.m_right = (_as_bytes(right[0]), _as_bytes(right[1]))
+        if len(self.m_left[0]) != len(self.m_left[1]) or len(self.m_right[0]) != len(self.m_right[1]):
+            raise ValueError("sequence and quality lengths differ")
+
+    def fast_merge(self, indexer: Indexer) -> Optional[MergedRead]:
+        """One pair through the C ABI (a one-thread launch; batches use fast_merge_device)."""
+        (ls, lq), (rs, rq) = self.m_left, self.m_right
+        cap = len(ls) + len(rs) + 1
+        oseq, oqual = C.create_string_buffer(cap), C.create_string_buffer(cap)
+        olen, odiff = C.c_int32(0), C.c_int32(0)
+        rc = _lib.check(_lib.lib().gf_fast_merge(indexer._handle(), ls, lq, len(ls), rs, rq, len(rs), oseq, oqual,
+                                                 C.byref(olen), C.byref(odiff)))
+        if rc == 0:
+            return None
+        return MergedRead(oseq.raw[:olen.value], oqual.raw[:olen.value], int(odiff.value))
+
+
+def pack_reads(seqs: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    if seqs:
+        np.cumsum([len(s) for s in seqs], out=off[1:])
+    return np.frombuffer(b"".join(seqs), dtype=np.uint8).copy(), off
+
+
+def fast_merge_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_quals, r_off, stream=None):
+    """Merge a batch of pairs resident in HBM.  Returns (bases, quals, offsets, diff): the
+    merged reads packed back to back in pair order — offsets int64[n+1], a pair that does not
+    merge has an empty slot — in the layout ``Indexer.map_reads_device`` takes, plus diff int32[n].
+    Two launches of gf_k_fast_merge (sizing, then writing) around one prefix sum."""
+    import torch
+    n = l_off.numel() - 1
+    dev = l_bases.device
+    for t in (l_bases, l_quals, r_bases, r_quals):
+        assert t.dtype == torch.uint8 and t.is_cuda
+    assert l_off.dtype == torch.int64 and r_off.dtype == torch.int64 and r_off.numel() == n + 1
+    st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    out_len = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    out_diff = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    L, h = _lib.lib(), indexer._handle()
+    args = (l_bases.data_ptr(), l_quals.data_ptr(), l_off.data_ptr(), r_bases.data_ptr(), r_quals.data_ptr(),
+            r_off.data_ptr(), n)
+    _lib.check(L.gf_fast_merge_device(h, *args, None, None, None, out_len.data_ptr(), out_diff.data_ptr(), st))
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    if n:
+        torch.cumsum(out_len[:n], 0, out=offsets[1:])
+    total = int(offsets[-1].item()) if n else 0
+    bases = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+    quals = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+    _lib.check(L.gf_fast_merge_device(h, *args, offsets.data_ptr(), bases.data_ptr(), quals.data_ptr(),
+                                      out_len.data_ptr(), out_diff.data_ptr(), st))
+    return bases[:total], quals[:total], offsets, out_diff[:n]
+
+
+def fast_merge_batch(indexer: Indexer, pairs: Sequence[SequenceReadPair]) -> List[Optional[MergedRead]]:
+    """Host convenience over fast_merge_device: upload, merge, download."""
+    import torch
+    if not pairs:
+        return []
+    dev = torch.device("cuda", indexer.info()["device"])
+    lb, lo = pack_reads([p.m_left[0] for p in pairs])
+    lq, _ = pack_reads([p.m_left[1] for p in pairs])
+    rb, ro = pack_reads([p.m_right[0] for p in pairs])
+    rq, _ = pack_reads([p.m_right[1] for p in pairs])
+    t = [torch.from_numpy(a).to(dev) for a in (lb, lq, lo, rb, rq, ro)]
+    bases, quals, off, diff = fast_merge_device(indexer, *t)
+    torch.cuda.synchronize(dev)
+    b, q, o, d = bases.cpu().numpy().tobytes(), quals.cpu().numpy().tobytes(), off.cpu().numpy(), diff.cpu().numpy()
+    return [MergedRead(b[o[i]:o[i + 1]], q[o[i]:o[i + 1]], int(d[i])) if o[i + 1] > o[i] else None
+            for i in range(len(pairs))]
+
+
+def scan_pair_end(mapper: FusionMapper, pairs: Sequence[SequenceReadPair]) -> List[List[ReadMatch]]:
+    """pescanner.rs:427-518 for a pack of pairs, three GPU steps instead of up to five
+    ``map_read`` calls per pair: merge all pairs; map the merged read of every pair that
+    merged and R1, R2 of every pair that did not (one batch); map the reverse complement of
+    every candidate that was mapable but gave no match (one smaller batch).  Returns, per
+    pair, the matches in the order the reference pushes them.  A match found on the reverse
+    complement of R1/R2 has ``m_reversed`` set (:489,:511); one found on the reverse
+    complement of a merged read has not (:465-468)."""
+    merged = fast_merge_batch(mapper.m_indexer, pairs)
+    cands: List[bytes] = []
+    owner: List[Tuple[int, bool]] = []  # (pair, is_merged)
+    for p, (pair, m) in enumerate(zip(pairs, merged)):
+        if m is not None:
+            cands.append(m.seq)
+            owner.append((p, True))
+        else:
+            cands.append(pair.m_left[0])
+            owner.append((p, False))
+            cands.append(pair.m_right[0])
+            owner.append((p, False))
+    first = mapper.map_reads(cands)
+    found: List[Optional[ReadMatch]] = [m for m, _ in first]
+    retry = [i for i, (m, mapable) in enumerate(first) if m is None and mapable]
+    if retry:
+        second = mapper.map_reads([reverse_complement(cands[i]) for i in retry])
+        for i, (m, _) in zip(retry, second):
+            if m is not None:
+                if not owner[i][1]:
+                    m.m_reversed = True
+                found[i] = m
+    out: List[List[ReadMatch]] = [[] for _ in pairs]
+    for i, m in enumerate(found):
+        if m is not None:
+            out[owner[i][0]].append(m)
+    return out

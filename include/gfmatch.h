@@ -192,6 +192,26 @@ int gf_index_fusion_map_read(const gf_index* idx, const uint8_t* gene_reversed, 
  * 640 symbols of the longer string, dynamic programming beyond */
 int64_t gf_edit_distance(const char* a, int64_t alen, const char* b, int64_t blen);
 
+/* --- the step before the path ----------------------------
+ * SequenceReadPair::fast_merge (read.rs:313-440) for a batch of pairs, device buffers on the
+ * index's device (the index only names the device; merging does not use it).  R1 = l_*,
+ * R2 = r_* as read from the FASTQ files (R2 not yet reverse-complemented), ASCII bases and
+ * Phred+33 qualities, offsets int64[n+1].  Merged read p is written at d_out_pos[p] (int64[n],
+ * chosen by the caller, room for len1+len2 bytes) of d_out_bases / d_out_quals;
+ * d_out_len[p] (int32) = merged length or 0 when the pair does not merge, d_out_diff[p]
+ * (int32) = the N of the reference's "merged_diff_N" name suffix.  d_out_bases == NULL is
+ * the sizing pass: only d_out_len / d_out_diff are written (d_out_pos, d_out_quals unused),
+ * so the caller can pack the merged reads back to back with one prefix sum and call again. */
+int gf_fast_merge_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
+                         const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets, int64_t n,
+                         const void* d_out_pos, void* d_out_bases, void* d_out_quals, void* d_out_len,
+                         void* d_out_diff, void* stream);
+/* One pair, host buffers (out_seq/out_qual: capacity len1+len2).  Returns 1 merged, 0 not
+ * merged, or a negative error.  Needs a HIP device like every compute entry point. */
+int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, int32_t len1, const char* r_seq,
+                  const char* r_qual, int32_t len2, char* out_seq, char* out_qual, int32_t* out_len,
+                  int32_t* out_diff);
+
 /* --- instrumentation -------------------------------------------------------
  * With profiling on, gf_map_reads_device brackets its mapping kernel with HIP
  * events on the launch stream; gf_last_map_kernel_ms synchronises on them and

@@ -230,3 +230,33 @@ def fusion_map_read(fusion_seq: Sequence[str], reversed_flags: Sequence[bool], r
         "left_distance": calc_ed(fusion_seq, read[:left_len], left[2], lpos - left_len + 1, lpos),
         "right_distance": calc_ed(fusion_seq, read[brk + 1:], right[2], rpos, rpos + right_len - 1),
     }
+
+
+# ---- SequenceReadPair::fast_merge (read.rs:313-440), from its description:
+# smallest overlap >= 30 whose mismatches are all "one side >= Q30, the other <= Q15" and fewer
+# than three; merged = left prefix + reverse-complemented right, overlap corrected.
+
+def fast_merge(l_seq: str, l_qual: str, r_seq: str, r_qual: str):
+    s2, q2 = revcomp(r_seq), r_qual[::-1]
+    n1, n2 = len(l_seq), len(s2)
+
+    def lowq(a: str, b: str) -> bool:
+        return (a >= "?" and b <= "0") or (a <= "0" and b >= "?")
+
+    for olen in range(30, min(n1, n2) + 1):
+        off = n1 - olen
+        mism = [i for i in range(olen) if l_seq[off + i] != s2[i]]
+        if all(lowq(l_qual[off + i], q2[i]) for i in mism) and len(mism) < 3:
+            seq = list(l_seq[:off] + s2)
+            qual = list(l_qual[:off] + q2)
+            for i in range(olen):
+                a, b = l_qual[off + i], q2[i]
+                if l_seq[off + i] != s2[i]:
+                    if a >= "?" and b <= "0":
+                        seq[off + i], qual[off + i] = l_seq[off + i], a
+                    else:
+                        seq[off + i], qual[off + i] = s2[i], b
+                else:
+                    qual[off + i] = chr(min(ord(a) + ord(b) - 33, ord("Z")))
+            return "".join(seq), "".join(qual), len(mism)
+    return None

@@ -11,7 +11,9 @@
 // make_index / map_read / segment_mask, so this oracle is
 // pinned only by (a) hand-derived known answers (SURVEY.md Appendix B,
 // tests/test_oracle_kat.py) and (b) agreement with a second, independently
-// written model (oracle/indexer_model.py).
+// written model (oracle/indexer_model.py).  One function here IS pinned by the
+// reference: orc_fast_merge reproduces the expected merged read of the reference's
+// unit test (read.rs:450-486; tests/golden/fast_merge_ref_test.json).
 //
 // The code is deliberately naive and keeps the reference's structure: an exact
 // 2^32-bit membership bitmap ("bloom filter"), a hash map k-mer -> GenePos with
@@ -629,6 +631,75 @@ int32_t orc_fusion_map_read(void* h, const uint8_t* reversed, const char* seq, i
   out->left_distance = calc_ed(ix->m_fusion_seq, left_seq, left.contig, left.position - left_len + 1, left.position);
   out->right_distance = calc_ed(ix->m_fusion_seq, right_seq, right.contig, right.position, right.position + right_len - 1);
   return 2;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// SequenceReadPair::fast_merge (src/core/read.rs:313-440), restated
+// literally.  Pinned by the reference's own asserting test (read.rs:450-486).
+// ---------------------------------------------------------------------------
+extern "C" {
+
+// left/right as read from the FASTQ pair (right NOT yet reverse-complemented).
+// Returns 1 and fills out_seq/out_qual (capacity len1 + len2), *out_len, *out_diff when the
+// pair merges, 0 otherwise.
+int32_t orc_fast_merge(const char* l_seq, const char* l_qual, int32_t len1, const char* r_seq, const char* r_qual,
+                       int32_t len2, char* out_seq, char* out_qual, int32_t* out_len, int32_t* out_diff) {
+  // :314 rc_right = m_right.reverse_complement(): sequence reverse-complemented, quality reversed
+  const std::string str1(l_seq, (size_t)len1), qual1(l_qual, (size_t)len1);
+  const std::string str2 = reverse_complement(std::string(r_seq, (size_t)len2));
+  std::string qual2(r_qual, (size_t)len2);
+  for (int32_t i = 0; i < len2 / 2; ++i) std::swap(qual2[(size_t)i], qual2[(size_t)(len2 - 1 - i)]);
+  const int32_t MIN_OVERLAP = 30;  // :325
+  bool overlapped = false;
+  int32_t olen = MIN_OVERLAP, diff = 0, low_qual_diff = 0;
+  while (olen <= std::min(len1, len2)) {  // :339-367
+    diff = 0;
+    low_qual_diff = 0;
+    bool ok = true;
+    const int32_t offset = len1 - olen;
+    for (int32_t i = 0; i < olen; ++i) {
+      if (str1[(size_t)(offset + i)] != str2[(size_t)i]) {
+        diff += 1;
+        if ((qual1[(size_t)(offset + i)] >= '?' && qual2[(size_t)i] <= '0') ||
+            (qual1[(size_t)(offset + i)] <= '0' && qual2[(size_t)i] >= '?'))
+          low_qual_diff += 1;
+        if (diff > low_qual_diff || low_qual_diff >= 3) {
+          ok = false;
+          break;
+        }
+      }
+    }
+    if (ok) {
+      overlapped = true;
+      break;
+    }
+    olen += 1;
+  }
+  if (!overlapped) return 0;
+  const int32_t offset = len1 - olen;  // :370
+  std::string ms = str1.substr(0, (size_t)offset) + str2;   // :380-386
+  std::string mq = qual1.substr(0, (size_t)offset) + qual2;  // :393-399
+  for (int32_t i = 0; i < olen; ++i) {  // :402-428
+    if (str1[(size_t)(offset + i)] != str2[(size_t)i]) {
+      if (qual1[(size_t)(offset + i)] >= '?' && qual2[(size_t)i] <= '0') {
+        ms[(size_t)(offset + i)] = str1[(size_t)(offset + i)];
+        mq[(size_t)(offset + i)] = qual1[(size_t)(offset + i)];
+      } else {
+        ms[(size_t)(offset + i)] = str2[(size_t)i];
+        mq[(size_t)(offset + i)] = qual2[(size_t)i];
+      }
+    } else {
+      uint32_t q = (uint32_t)(unsigned char)qual1[(size_t)(offset + i)] + (uint32_t)(unsigned char)qual2[(size_t)i] - 33u;
+      mq[(size_t)(offset + i)] = q >= (uint32_t)'Z' ? 'Z' : (char)q;
+    }
+  }
+  memcpy(out_seq, ms.data(), ms.size());
+  memcpy(out_qual, mq.data(), mq.size());
+  *out_len = (int32_t)ms.size();
+  *out_diff = diff;
+  return 1;
 }
 
 }  // extern "C"

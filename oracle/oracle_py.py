@@ -64,6 +64,9 @@ def lib() -> C.CDLL:
     L.orc_edit_distance.restype = i64
     L.orc_fusion_map_read.argtypes = [vp, vp, C.c_char_p, i64, vp, i32, vp]
     L.orc_fusion_map_read.restype = i32
+    L.orc_fast_merge.argtypes = [C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p,
+                                 C.POINTER(i32), C.POINTER(i32)]
+    L.orc_fast_merge.restype = i32
     _lib = L
     return L
 
@@ -191,3 +194,15 @@ def fusion_map_read(ox: "OracleIndexer", reversed_flags: Sequence[bool], seq: by
     st = int(lib().orc_fusion_map_read(ox._h, rev.ctypes.data, seq, len(seq), arr.ctypes.data, len(mapping),
                                        out.ctypes.data))
     return st, ({k: int(out[0][k]) for k in ORC_READMATCH.names} if st == 2 else None)
+
+
+def fast_merge(l_seq: bytes, l_qual: bytes, r_seq: bytes, r_qual: bytes):
+    """SequenceReadPair::fast_merge: (merged_seq, merged_qual, diff) or None."""
+    cap = len(l_seq) + len(r_seq) + 1
+    oseq, oqual = C.create_string_buffer(cap), C.create_string_buffer(cap)
+    olen, odiff = C.c_int32(0), C.c_int32(0)
+    ok = lib().orc_fast_merge(l_seq, l_qual, len(l_seq), r_seq, r_qual, len(r_seq), oseq, oqual, C.byref(olen),
+                              C.byref(odiff))
+    if not ok:
+        return None
+    return oseq.raw[:olen.value], oqual.raw[:olen.value], int(odiff.value)

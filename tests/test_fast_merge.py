@@ -1,0 +1,234 @@
+"""SequenceReadPair::fast_merge (read.rs:313-440) and the pair policy of
+PairEndScanner::scan_pair_end (pescanner.rs:427-518).
+
+CPU: the two restatements against the reference's own unit test (read.rs:450-486, kept as
+data in tests/golden/fast_merge_ref_test.json) and against each other on seeded pairs that
+reach every branch.  GPU: the device kernel behind the C ABI against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import indexer_model as M
+from tests.helpers import rand_seq, rc
+
+HERE = os.path.dirname(__file__)
+REF_TEST = os.path.join(HERE, "golden", "fast_merge_ref_test.json")
+GOLDEN = os.path.join(HERE, "golden", "branch_cases.json")
+
+
+def make_pairs(seed: int, n: int, read_len=(100, 151)):
+    """Seeded pairs: fragments shorter than 2*len-30 overlap; mismatches of every class
+    (high/high, high/low, low/high, low/low) are planted in the overlap, plus N bases,
+    lower case, ragged lengths, pairs shorter than the minimum overlap, empty reads and
+    fragments shorter than the reads (R2 runs past the start of R1)."""
+    rng = np.random.default_rng(seed)
+    quals_hi = b"?@ABCDEFGHIJ"
+    quals_lo = b"#$%&'()*+,-./0"
+    quals_mid = b"123456789:;<=>"
+    pairs = []
+    for k in range(n):
+        l1 = int(rng.integers(*read_len))
+        l2 = int(rng.integers(*read_len))
+        kind = k % 10
+        if kind == 0:
+            frag = int(rng.integers(l1 + l2 - 29, l1 + l2 + 200))       # no overlap >= 30
+        elif kind == 1:
+            frag = l1 + l2 - int(rng.integers(28, 33))                   # around the minimum
+        elif kind == 2:
+            frag = max(l1, l2)                                           # one read covers the fragment
+        elif kind == 3:
+            l1, l2 = int(rng.integers(0, 40)), int(rng.integers(0, 40))  # very short / empty reads
+            frag = max(l1, l2, 1) + int(rng.integers(0, 10))
+        else:
+            frag = int(rng.integers(max(l1, l2), l1 + l2 - 29))
+        if kind == 4 and k % 20 == 4:
+            unit = rand_seq(rng, int(rng.integers(1, 6)))                # tandem repeat: several overlaps fit
+            f = (unit * (frag // len(unit) + 1))[:frag]
+        else:
+            f = rand_seq(rng, frag)
+        s1 = bytearray(f[:l1])
+        s2 = bytearray(rc(f)[:l2])
+        l1, l2 = len(s1), len(s2)
+        q1 = bytearray(rng.choice(np.frombuffer(quals_hi, np.uint8), size=l1).tobytes())
+        q2 = bytearray(rng.choice(np.frombuffer(quals_hi, np.uint8), size=l2).tobytes())
+        ov = l1 + l2 - frag
+        if ov > 0 and kind >= 4:
+            for _ in range(int(rng.integers(0, 5))):
+                i = int(rng.integers(0, ov))          # overlap column i: s1[l1-ov+i] vs rc(s2)[i] = s2[l2-1-i]
+                a, b = l1 - ov + i, l2 - 1 - i
+                if not (0 <= a < l1 and 0 <= b < l2):
+                    continue
+                cls = int(rng.integers(0, 6))
+                s1[a] = ord(rng.choice(list("ACGTNa")))
+                pick = lambda t: int(rng.choice(np.frombuffer(t, np.uint8)))  # noqa: E731
+                if cls == 0:
+                    q1[a], q2[b] = pick(quals_hi), pick(quals_lo)
+                elif cls == 1:
+                    q1[a], q2[b] = pick(quals_lo), pick(quals_hi)
+                elif cls == 2:
+                    q1[a], q2[b] = pick(quals_lo), pick(quals_lo)
+                elif cls == 3:
+                    q1[a], q2[b] = pick(quals_mid), pick(quals_lo)
+                elif cls == 4:
+                    q1[a], q2[b] = ord("?"), ord("0")                   # exactly on both thresholds
+                else:
+                    q1[a], q2[b] = ord(">"), ord("0")                   # one below Q30
+        if kind == 5:
+            q1 = bytearray(b"Z" * l1)                                    # quality sum saturates at 'Z'
+        pairs.append((bytes(s1), bytes(q1), bytes(s2), bytes(q2)))
+    return pairs
+
+
+def test_reference_unit_test_vector(oracle):
+    """read.rs:450-486: the merged sequence the reference's own test expects."""
+    g = json.load(open(REF_TEST))
+    ls, lq, rs, rq = (g[k].encode() for k in ("left_seq", "left_qual", "right_seq", "right_qual"))
+    got = oracle.fast_merge(ls, lq, rs, rq)
+    assert got is not None and got[0].decode() == g["merged_seq"] and len(got[1]) == len(got[0])
+    mod = M.fast_merge(ls.decode(), lq.decode(), rs.decode(), rq.decode())
+    assert mod is not None and mod[0] == g["merged_seq"]
+    assert (got[0].decode(), got[1].decode(), got[2]) == mod
+
+
+def test_oracle_and_model_agree():
+    from oracle import oracle_py
+    pairs = make_pairs(3, 600)
+    merged = diffs = 0
+    for ls, lq, rs, rq in pairs:
+        a = oracle_py.fast_merge(ls, lq, rs, rq)
+        b = M.fast_merge(ls.decode(), lq.decode(), rs.decode(), rq.decode())
+        if a is None:
+            assert b is None
+            continue
+        assert (a[0].decode(), a[1].decode(), a[2]) == b
+        merged += 1
+        diffs += a[2] > 0
+    assert merged >= 200 and diffs >= 20 and merged < len(pairs)
+
+
+def test_merge_properties(oracle):
+    """Size-independent properties: a merged read starts with R1's non-overlapping prefix
+    and ends with rc(R2)'s non-overlapping suffix; a perfect overlap reproduces the fragment."""
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        frag = rand_seq(rng, int(rng.integers(160, 260)))
+        l = 150
+        s1, s2 = frag[:l], rc(frag)[:l]
+        q = b"E" * l
+        got = oracle.fast_merge(s1, q, s2, q)
+        assert got is not None and got[0] == frag and got[2] == 0
+        ov = 2 * l - len(frag)
+        assert got[1] == b"E" * (l - ov) + b"Z" * ov + b"E" * (l - ov)
+
+
+@pytest.mark.gpu
+def test_fast_merge_device_parity(gpu_device, oracle):
+    import torch
+    from genefuserust_amd import Indexer
+    from genefuserust_amd.read_pair import SequenceReadPair, fast_merge_batch, fast_merge_device, pack_reads
+    g = json.load(open(GOLDEN))
+    ix = Indexer.from_gene_slices([None if x is None else x.encode() for x in g["genes"]], g["reversed"])
+    ix.make_index()
+    ref = json.load(open(REF_TEST))
+    pairs = [tuple(ref[k].encode() for k in ("left_seq", "left_qual", "right_seq", "right_qual"))]
+    pairs += make_pairs(9, 4000) + make_pairs(10, 300, read_len=(240, 301))
+    want = [oracle.fast_merge(*p) for p in pairs]
+    got = fast_merge_batch(ix, [SequenceReadPair((p[0], p[1]), (p[2], p[3])) for p in pairs])
+    assert got[0] is not None and got[0].seq.decode() == ref["merged_seq"]
+    n_merged = 0
+    for k, (w, m) in enumerate(zip(want, got)):
+        if w is None:
+            assert m is None, k
+        else:
+            assert m is not None and (m.seq, m.quality, m.diff) == w, k
+            n_merged += 1
+    assert 1000 < n_merged < len(pairs)
+    # one pair through the host entry point
+    for k in (0, 5, 14, 27):
+        p = pairs[k]
+        one = SequenceReadPair((p[0], p[1]), (p[2], p[3])).fast_merge(ix)
+        assert (None if one is None else tuple(one)) == want[k]
+    # empty batch and the device form's layout (offsets are the prefix sum of merged lengths)
+    assert fast_merge_batch(ix, []) == []
+    dev = torch.device("cuda", gpu_device)
+    lb, lo = pack_reads([p[0] for p in pairs]); lq, _ = pack_reads([p[1] for p in pairs])
+    rb, ro = pack_reads([p[2] for p in pairs]); rq, _ = pack_reads([p[3] for p in pairs])
+    t = [torch.from_numpy(a).to(dev) for a in (lb, lq, lo, rb, rq, ro)]
+    bases, quals, off, diff = fast_merge_device(ix, *t)
+    lens = (off[1:] - off[:-1]).cpu().numpy()
+    assert [int(x) for x in lens] == [0 if w is None else len(w[0]) for w in want]
+    assert bases.numel() == int(lens.sum()) == quals.numel()
+    # merged reads go straight into the mapping kernel: same hits as mapping the oracle's strings
+    counts, matches = ix.map_reads_device(bases, off, int(lens.max()))
+    torch.cuda.synchronize()
+    ox = oracle.OracleIndexer([None if x is None else x.encode() for x in g["genes"]])
+    cn = counts.cpu().numpy()
+    for k in range(0, len(pairs), 97):
+        w = want[k]
+        assert int(cn[k]) == (0 if w is None else len(ox.map_read(w[0])))
+    ix.close()
+
+
+@pytest.mark.gpu
+def test_scan_pair_end_policy(gpu_device, oracle):
+    """pescanner.rs:427-518 on pairs cut from planted fusions: merged pairs are searched as
+    one read (and its reverse complement without the reversed flag); the others as R1 and R2
+    (reverse complements flagged)."""
+    from genefuserust_amd import FusionMapper, Indexer
+    from genefuserust_amd.read_pair import SequenceReadPair, scan_pair_end
+    g = json.load(open(GOLDEN))
+    genes = [None if x is None else x.encode() for x in g["genes"]]
+    ix = Indexer.from_gene_slices(genes, g["reversed"])
+    ix.make_index()
+    fm = FusionMapper(ix)
+    ox = oracle.OracleIndexer(genes)
+    rng = np.random.default_rng(21)
+    g0, g1 = genes[0], genes[1]
+    pairs = []
+    for k in range(120):
+        p, q = int(rng.integers(300, 2600)), int(rng.integers(300, 2200))
+        frag = g0[p - 150:p] + g1[q:q + 150] if k % 3 else rand_seq(rng, 300)
+        lo = int(rng.integers(0, 60))
+        flen = int(rng.integers(150, 300 - lo))
+        f = frag[lo:lo + flen]
+        if k % 2:
+            f = rc(f)
+        rl = min(150, len(f))
+        s1, s2 = f[:rl], rc(f)[:rl]
+        pairs.append(SequenceReadPair((s1, b"E" * rl), (s2, b"E" * rl)))
+    got = scan_pair_end(fm, pairs)
+
+    def ref_map(seq):
+        return oracle.fusion_map_read(ox, g["reversed"], seq, ox.map_read(seq))
+
+    def ref_scan_one(seq, flag_rc):
+        st, rm = ref_map(seq)
+        if st == 2:
+            return [(rm, False)]
+        if st == 1:
+            st, rm = ref_map(rc(seq))
+            if st == 2:
+                return [(rm, flag_rc)]
+        return []
+
+    n_match = n_merged = n_rev = 0
+    for pair, res in zip(pairs, got):
+        m = oracle.fast_merge(pair.m_left[0], pair.m_left[1], pair.m_right[0], pair.m_right[1])
+        if m is not None:
+            n_merged += 1
+            want = ref_scan_one(m[0], False)
+        else:
+            want = ref_scan_one(pair.m_left[0], True) + ref_scan_one(pair.m_right[0], True)
+        assert len(res) == len(want)
+        for r, (rm, rev) in zip(res, want):
+            n_match += 1
+            n_rev += rev
+            assert r.m_reversed == rev
+            assert (r.m_read_break, r.m_gap, r.m_left_distance, r.m_right_distance) == (
+                rm["read_break"], rm["gap"], rm["left_distance"], rm["right_distance"])
+            assert (r.m_left_gp, r.m_right_gp) == ((rm["left_contig"], rm["left_position"]),
+                                                    (rm["right_contig"], rm["right_position"]))
+    assert n_merged >= 30 and n_match >= 20
+    ix.close()
