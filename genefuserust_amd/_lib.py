@@ -120,7 +120,11 @@ def lib() -> C.CDLL:
     L.gf_fusion_map_read.restype = C.c_int
     L.gf_index_fusion_map_read.argtypes = [vp, vp, C.c_char_p, i64, C.POINTER(GfSeqMatch), i32, C.POINTER(GfReadMatch)]
     L.gf_index_fusion_map_read.restype = C.c_int
-    L.gf_fast_merge_device.argtypes = [vp] * 7 + [i64] + [vp] * 6
+    L.gf_fast_merge_find_device.argtypes = [vp] * 7 + [i64, i32] + [vp] * 3
+    L.gf_fast_merge_find_device.restype = C.c_int
+    L.gf_fast_merge_write_device.argtypes = [vp] * 7 + [i64] + [vp] * 5
+    L.gf_fast_merge_write_device.restype = C.c_int
+    L.gf_fast_merge_device.argtypes = [vp] * 7 + [i64, i32] + [vp] * 6
     L.gf_fast_merge_device.restype = C.c_int
     L.gf_fast_merge.argtypes = [vp, C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p,
                                 C.POINTER(i32), C.POINTER(i32)]

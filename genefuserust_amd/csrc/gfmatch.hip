@@ -129,6 +129,22 @@ struct gf_index {
   }
 };
 
+static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** out) {
+  gf_index::Workspace& W = mix->ws[st];  // caller holds ws_mu
+  if (W.bytes < need) {
+    if (W.base) {
+      GF_HIP(hipStreamSynchronize(st));  // earlier calls on this stream may still use it
+      GF_HIP(hipFree(W.base));
+      W.base = nullptr;
+      W.bytes = 0;
+    }
+    GF_HIP(hipMalloc(&W.base, need));
+    W.bytes = need;
+  }
+  *out = W.base;
+  return GF_OK;
+}
+
 extern "C" {
 
 const char* gf_last_error(void) { return g_err.c_str(); }
@@ -408,18 +424,12 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     const size_t sz_ctr = 256;
     const size_t need = sz_pkg + sz_ivg + sz_lb + sz_lc + sz_bc + sz_ctr;
     std::lock_guard<std::mutex> ws_lock(mix->ws_mu);  // held until this call's launches are queued
-    gf_index::Workspace& W = mix->ws[st];
-    if (W.bytes < need) {
-      if (W.base) {
-        GF_HIP(hipStreamSynchronize(st));  // earlier calls on this stream may still use it
-        GF_HIP(hipFree(W.base));
-        W.base = nullptr;
-        W.bytes = 0;
-      }
-      GF_HIP(hipMalloc(&W.base, need));
-      W.bytes = need;
+    void* ws_base = nullptr;
+    {
+      int wrc = acquire_workspace(mix, st, need, &ws_base);
+      if (wrc != GF_OK) return wrc;
     }
-    uint8_t* wp = (uint8_t*)W.base;
+    uint8_t* wp = (uint8_t*)ws_base;
     uint32_t* pkg = (uint32_t*)wp; wp += sz_pkg;
     uint32_t* ivg = (uint32_t*)wp; wp += sz_ivg;
     GfPipeEntry* list_b = (GfPipeEntry*)wp; wp += sz_lb;
@@ -777,22 +787,88 @@ int gf_index_fusion_map_read(const gf_index* idx, const uint8_t* gene_reversed, 
 }
 
 // ---- SequenceReadPair::fast_merge on the device ----
-int gf_fast_merge_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
-                         const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets, int64_t n,
-                         const void* d_out_pos, void* d_out_bases, void* d_out_quals, void* d_out_len,
-                         void* d_out_diff, void* stream) {
-  if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
+int gf_fast_merge_find_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
+                              const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,
+                              const void* d_r_offsets, int64_t n, int32_t max_read_len, void* d_out_len,
+                              void* d_out_diff, void* stream) {
+  if (!idx || n < 0 || max_read_len < 0) return fail(GF_ERR_ARG, "null index, negative n or max_read_len");
   if (n == 0) return GF_OK;
-  if (!d_l_offsets || !d_r_offsets || !d_out_len || !d_out_diff) return fail(GF_ERR_ARG, "null device pointer");
-  if (d_out_bases && (!d_out_pos || !d_out_quals)) return fail(GF_ERR_ARG, "out_bases without out_pos/out_quals");
+  if (!d_l_bases || !d_l_quals || !d_l_offsets || !d_r_bases || !d_r_quals || !d_r_offsets || !d_out_len ||
+      !d_out_diff)
+    return fail(GF_ERR_ARG, "null device pointer");
   DeviceGuard guard(idx->device);
+  gf_index* mix = const_cast<gf_index*>(idx);
+  hipStream_t st = (hipStream_t)stream;
+  const uint8_t* lb = (const uint8_t*)d_l_bases; const uint8_t* lq = (const uint8_t*)d_l_quals;
+  const uint8_t* rb = (const uint8_t*)d_r_bases; const uint8_t* rq = (const uint8_t*)d_r_quals;
+  const int64_t* lo = (const int64_t*)d_l_offsets; const int64_t* ro = (const int64_t*)d_r_offsets;
   const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 32);
-  hipLaunchKernelGGL(gf_k_fast_merge, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_l_bases,
-                     (const uint8_t*)d_l_quals, (const int64_t*)d_l_offsets, (const uint8_t*)d_r_bases,
-                     (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int64_t*)d_out_pos,
-                     (uint8_t*)d_out_bases, (uint8_t*)d_out_quals, (int32_t*)d_out_len, (int32_t*)d_out_diff);
+  if (max_read_len > 256) {  // beyond the packed kernels' word budget: the byte loop for every pair
+    hipLaunchKernelGGL(gf_k_merge_find_bytes, dim3(grid), dim3(256), 0, st, lb, lq, lo, rb, rq, ro, n,
+                       (int32_t*)d_out_len, (int32_t*)d_out_diff);
+    GF_HIP(hipGetLastError());
+    return GF_OK;
+  }
+  // packed streams of both buffers: n * lmax bases each from the first read on; pairs that lie
+  // beyond them (gaps, reads longer than max_read_len) take the byte loop inside the kernel
+  const int lmax = std::max(max_read_len, 32);
+  const uint64_t cap_chunks = ((uint64_t)n * (uint64_t)lmax + 15) / 16 + 8;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t sz_pkg = al((cap_chunks + 64) * sizeof(uint32_t));
+  const size_t sz_ivg = al((cap_chunks / 2 + 64) * sizeof(uint32_t));
+  std::lock_guard<std::mutex> ws_lock(mix->ws_mu);  // held until this call's launches are queued
+  void* base = nullptr;
+  int rc = acquire_workspace(mix, st, 2 * (sz_pkg + sz_ivg), &base);
+  if (rc != GF_OK) return rc;
+  uint8_t* wp = (uint8_t*)base;
+  uint32_t* pkg1 = (uint32_t*)wp; wp += sz_pkg;
+  uint32_t* ivg1 = (uint32_t*)wp; wp += sz_ivg;
+  uint32_t* pkg2 = (uint32_t*)wp; wp += sz_pkg;
+  uint32_t* ivg2 = (uint32_t*)wp;
+  GfStream S1, S2;
+  S1.pkg = pkg1; S1.ivg = ivg1; S1.cap_bases = cap_chunks * 16;
+  S2.pkg = pkg2; S2.ivg = ivg2; S2.cap_bases = cap_chunks * 16;
+  const int g_pack = (int)std::min<uint64_t>((cap_chunks + 255) / 256, (uint64_t)idx->n_cus * 64);
+  hipLaunchKernelGGL(gf_k_pack, dim3(g_pack), dim3(256), 0, st, lb, lo, n, cap_chunks, pkg1, (uint16_t*)ivg1);
+  hipLaunchKernelGGL(gf_k_pack_rc, dim3(g_pack), dim3(256), 0, st, rb, ro, n, cap_chunks, pkg2, (uint16_t*)ivg2);
+  if (max_read_len <= 160)
+    hipLaunchKernelGGL((gf_k_merge_find<10>), dim3(grid), dim3(256), 0, st, S1, S2, lb, lq, lo, rb, rq, ro, n,
+                       (int32_t*)d_out_len, (int32_t*)d_out_diff);
+  else
+    hipLaunchKernelGGL((gf_k_merge_find<16>), dim3(grid), dim3(256), 0, st, S1, S2, lb, lq, lo, rb, rq, ro, n,
+                       (int32_t*)d_out_len, (int32_t*)d_out_diff);
   GF_HIP(hipGetLastError());
   return GF_OK;
+}
+
+int gf_fast_merge_write_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
+                               const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,
+                               const void* d_r_offsets, int64_t n, const void* d_len, const void* d_out_pos,
+                               void* d_out_bases, void* d_out_quals, void* stream) {
+  if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
+  if (n == 0) return GF_OK;
+  if (!d_l_bases || !d_l_quals || !d_l_offsets || !d_r_bases || !d_r_quals || !d_r_offsets || !d_len ||
+      !d_out_pos || !d_out_bases || !d_out_quals)
+    return fail(GF_ERR_ARG, "null device pointer");
+  DeviceGuard guard(idx->device);
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 32);
+  hipLaunchKernelGGL(gf_k_merge_write, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_l_bases,
+                     (const uint8_t*)d_l_quals, (const int64_t*)d_l_offsets, (const uint8_t*)d_r_bases,
+                     (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int32_t*)d_len,
+                     (const int64_t*)d_out_pos, (uint8_t*)d_out_bases, (uint8_t*)d_out_quals);
+  GF_HIP(hipGetLastError());
+  return GF_OK;
+}
+
+int gf_fast_merge_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
+                         const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets, int64_t n,
+                         int32_t max_read_len, const void* d_out_pos, void* d_out_bases, void* d_out_quals,
+                         void* d_out_len, void* d_out_diff, void* stream) {
+  int rc = gf_fast_merge_find_device(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n,
+                                     max_read_len, d_out_len, d_out_diff, stream);
+  if (rc != GF_OK) return rc;
+  return gf_fast_merge_write_device(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n,
+                                    d_out_len, d_out_pos, d_out_bases, d_out_quals, stream);
 }
 
 int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, int32_t len1, const char* r_seq,
@@ -804,8 +880,9 @@ int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, in
   DevBuf<uint8_t> dl, dlq, dr, drq, dob, doq;
   DevBuf<int64_t> dlo, dro, dpos;
   DevBuf<int32_t> dlen, ddiff;
-  GF_HIP(dl.alloc((size_t)len1 + 1)); GF_HIP(dlq.alloc((size_t)len1 + 1));
-  GF_HIP(dr.alloc((size_t)len2 + 1)); GF_HIP(drq.alloc((size_t)len2 + 1));
+  // +64: the packing kernels read whole 16-byte chunks
+  GF_HIP(dl.alloc((size_t)len1 + 64)); GF_HIP(dlq.alloc((size_t)len1 + 64));
+  GF_HIP(dr.alloc((size_t)len2 + 64)); GF_HIP(drq.alloc((size_t)len2 + 64));
   GF_HIP(dob.alloc((size_t)len1 + len2 + 1)); GF_HIP(doq.alloc((size_t)len1 + len2 + 1));
   GF_HIP(dlo.alloc(2)); GF_HIP(dro.alloc(2)); GF_HIP(dpos.alloc(1)); GF_HIP(dlen.alloc(1)); GF_HIP(ddiff.alloc(1));
   const int64_t lo[2] = {0, len1}, ro[2] = {0, len2}, pos0 = 0;
@@ -814,8 +891,8 @@ int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, in
   GF_HIP(hipMemcpy(dlo.p, lo, sizeof lo, hipMemcpyHostToDevice));
   GF_HIP(hipMemcpy(dro.p, ro, sizeof ro, hipMemcpyHostToDevice));
   GF_HIP(hipMemcpy(dpos.p, &pos0, sizeof pos0, hipMemcpyHostToDevice));
-  int rc = gf_fast_merge_device(idx, dl.p, dlq.p, dlo.p, dr.p, drq.p, dro.p, 1, dpos.p, dob.p, doq.p, dlen.p, ddiff.p,
-                                nullptr);
+  int rc = gf_fast_merge_device(idx, dl.p, dlq.p, dlo.p, dr.p, drq.p, dro.p, 1, std::max(len1, len2), dpos.p, dob.p,
+                                doq.p, dlen.p, ddiff.p, nullptr);
   if (rc != GF_OK) return rc;
   GF_HIP(hipDeviceSynchronize());
   GF_HIP(hipMemcpy(out_len, dlen.p, sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -54,11 +54,12 @@ def pack_reads(seqs: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
     return np.frombuffer(b"".join(seqs), dtype=np.uint8).copy(), off
 
 
-def fast_merge_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_quals, r_off, stream=None):
+def fast_merge_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_quals, r_off, max_read_len: int,
+                      stream=None):
     """Merge a batch of pairs resident in HBM.  Returns (bases, quals, offsets, diff): the
     merged reads packed back to back in pair order — offsets int64[n+1], a pair that does not
     merge has an empty slot — in the layout ``Indexer.map_reads_device`` takes, plus diff int32[n].
-    Two launches of gf_k_fast_merge (sizing, then writing) around one prefix sum."""
+    gf_fast_merge_find_device, one prefix sum, gf_fast_merge_write_device."""
     import torch
     n = l_off.numel() - 1
     dev = l_bases.device
@@ -71,15 +72,15 @@ def fast_merge_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_qual
     L, h = _lib.lib(), indexer._handle()
     args = (l_bases.data_ptr(), l_quals.data_ptr(), l_off.data_ptr(), r_bases.data_ptr(), r_quals.data_ptr(),
             r_off.data_ptr(), n)
-    _lib.check(L.gf_fast_merge_device(h, *args, None, None, None, out_len.data_ptr(), out_diff.data_ptr(), st))
+    _lib.check(L.gf_fast_merge_find_device(h, *args, int(max_read_len), out_len.data_ptr(), out_diff.data_ptr(), st))
     offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     if n:
         torch.cumsum(out_len[:n], 0, out=offsets[1:])
     total = int(offsets[-1].item()) if n else 0
     bases = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
     quals = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
-    _lib.check(L.gf_fast_merge_device(h, *args, offsets.data_ptr(), bases.data_ptr(), quals.data_ptr(),
-                                      out_len.data_ptr(), out_diff.data_ptr(), st))
+    _lib.check(L.gf_fast_merge_write_device(h, *args, out_len.data_ptr(), offsets.data_ptr(), bases.data_ptr(),
+                                            quals.data_ptr(), st))
     return bases[:total], quals[:total], offsets, out_diff[:n]
 
 
@@ -94,7 +95,8 @@ def fast_merge_batch(indexer: Indexer, pairs: Sequence[SequenceReadPair]) -> Lis
     rb, ro = pack_reads([p.m_right[0] for p in pairs])
     rq, _ = pack_reads([p.m_right[1] for p in pairs])
     t = [torch.from_numpy(a).to(dev) for a in (lb, lq, lo, rb, rq, ro)]
-    bases, quals, off, diff = fast_merge_device(indexer, *t)
+    max_len = int(max(np.diff(lo).max(), np.diff(ro).max()))
+    bases, quals, off, diff = fast_merge_device(indexer, *t, max_len)
     torch.cuda.synchronize(dev)
     b, q, o, d = bases.cpu().numpy().tobytes(), quals.cpu().numpy().tobytes(), off.cpu().numpy(), diff.cpu().numpy()
     return [MergedRead(b[o[i]:o[i + 1]], q[o[i]:o[i + 1]], int(d[i])) if o[i + 1] > o[i] else None

@@ -194,18 +194,33 @@ int64_t gf_edit_distance(const char* a, int64_t alen, const char* b, int64_t ble
 
 /* --- the step before the path ----------------------------
  * SequenceReadPair::fast_merge (read.rs:313-440) for a batch of pairs, device buffers on the
- * index's device (the index only names the device; merging does not use it).  R1 = l_*,
- * R2 = r_* as read from the FASTQ files (R2 not yet reverse-complemented), ASCII bases and
- * Phred+33 qualities, offsets int64[n+1].  Merged read p is written at d_out_pos[p] (int64[n],
- * chosen by the caller, room for len1+len2 bytes) of d_out_bases / d_out_quals;
- * d_out_len[p] (int32) = merged length or 0 when the pair does not merge, d_out_diff[p]
- * (int32) = the N of the reference's "merged_diff_N" name suffix.  d_out_bases == NULL is
- * the sizing pass: only d_out_len / d_out_diff are written (d_out_pos, d_out_quals unused),
- * so the caller can pack the merged reads back to back with one prefix sum and call again. */
+ * index's device (the index names the device and owns the per-stream workspace; the merge
+ * does not look at the table).  R1 = l_*, R2 = r_* as read from the FASTQ files (R2 not
+ * reverse-complemented), ASCII bases and Phred+33 qualities, offsets int64[n+1] (pair p =
+ * bytes offsets[p] .. offsets[p+1] of its buffers, the same offsets for bases and qualities).
+ *
+ * gf_fast_merge_find_device: d_out_len[p] (int32) = length of the merged read, 0 when the
+ *   pair does not merge; d_out_diff[p] (int32) = the N of the reference's "merged_diff_N"
+ *   name suffix (read.rs:372).  max_read_len sizes the workspace (packed copies of both
+ *   buffers); pairs with a longer read are still merged exactly, by a slower byte loop.
+ * gf_fast_merge_write_device: writes merged read p (d_len[p] > 0, as produced by _find) at
+ *   d_out_pos[p] (int64[n], chosen by the caller — typically the prefix sum of d_len, which
+ *   packs the merged reads back to back in the layout gf_map_reads_device takes) of
+ *   d_out_bases / d_out_quals.
+ * gf_fast_merge_device: both steps, for callers whose d_out_pos does not depend on the
+ *   lengths (e.g. one slot of len1+len2 bytes per pair). */
+int gf_fast_merge_find_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
+                              const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,
+                              const void* d_r_offsets, int64_t n, int32_t max_read_len, void* d_out_len,
+                              void* d_out_diff, void* stream);
+int gf_fast_merge_write_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
+                               const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,
+                               const void* d_r_offsets, int64_t n, const void* d_len, const void* d_out_pos,
+                               void* d_out_bases, void* d_out_quals, void* stream);
 int gf_fast_merge_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
                          const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets, int64_t n,
-                         const void* d_out_pos, void* d_out_bases, void* d_out_quals, void* d_out_len,
-                         void* d_out_diff, void* stream);
+                         int32_t max_read_len, const void* d_out_pos, void* d_out_bases, void* d_out_quals,
+                         void* d_out_len, void* d_out_diff, void* stream);
 /* One pair, host buffers (out_seq/out_qual: capacity len1+len2).  Returns 1 merged, 0 not
  * merged, or a negative error.  Needs a HIP device like every compute entry point. */
 int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, int32_t len1, const char* r_seq,

@@ -123,51 +123,93 @@ def test_merge_properties(oracle):
         assert got[1] == b"E" * (l - ov) + b"Z" * ov + b"E" * (l - ov)
 
 
-@pytest.mark.gpu
-def test_fast_merge_device_parity(gpu_device, oracle):
+def _device_merge(ix, pairs, max_read_len):
     import torch
+    from genefuserust_amd.read_pair import fast_merge_device, pack_reads
+    dev = torch.device("cuda", 0)
+    lb, lo = pack_reads([p[0] for p in pairs]); lq, _ = pack_reads([p[1] for p in pairs])
+    rb, ro = pack_reads([p[2] for p in pairs]); rq, _ = pack_reads([p[3] for p in pairs])
+    t = [torch.from_numpy(a).to(dev) for a in (lb, lq, lo, rb, rq, ro)]
+    bases, quals, off, diff = fast_merge_device(ix, *t, max_read_len)
+    torch.cuda.synchronize()
+    b, q, o, d = bases.cpu().numpy().tobytes(), quals.cpu().numpy().tobytes(), off.cpu().numpy(), diff.cpu().numpy()
+    got = [(b[o[i]:o[i + 1]], q[o[i]:o[i + 1]], int(d[i])) if o[i + 1] > o[i] else None for i in range(len(pairs))]
+    return got, (bases, off)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["w10", "w16", "bytes", "hint-too-small", "gaps"])
+def test_fast_merge_device_parity(gpu_device, oracle, case):
+    """Every route through gf_fast_merge_find_device: the packed kernels for reads of up to
+    160 / 256 bases, the byte loop for longer reads, and batches whose max_read_len hint is
+    too small (the stream does not cover the batch; those pairs take the byte loop inside
+    the packed kernel)."""
     from genefuserust_amd import Indexer
-    from genefuserust_amd.read_pair import SequenceReadPair, fast_merge_batch, fast_merge_device, pack_reads
     g = json.load(open(GOLDEN))
     ix = Indexer.from_gene_slices([None if x is None else x.encode() for x in g["genes"]], g["reversed"])
     ix.make_index()
     ref = json.load(open(REF_TEST))
-    pairs = [tuple(ref[k].encode() for k in ("left_seq", "left_qual", "right_seq", "right_qual"))]
-    pairs += make_pairs(9, 4000) + make_pairs(10, 300, read_len=(240, 301))
+    ref_pair = tuple(ref[k].encode() for k in ("left_seq", "left_qual", "right_seq", "right_qual"))
+    if case == "w10":
+        pairs, hint = [ref_pair] + make_pairs(9, 6000), 151
+    elif case == "w16":
+        pairs, hint = [ref_pair] + make_pairs(10, 1500, read_len=(150, 257)), 256
+    elif case == "bytes":
+        pairs, hint = [ref_pair] + make_pairs(11, 300, read_len=(240, 301)), 300
+    elif case == "hint-too-small":
+        pairs, hint = [ref_pair] + make_pairs(12, 1500, read_len=(100, 200)), 120
+    else:  # reads of very different lengths: most of the batch lies beyond n * max_read_len
+        pairs, hint = [ref_pair] + make_pairs(13, 400, read_len=(100, 151)) + make_pairs(14, 40, read_len=(250, 300)) \
+            + make_pairs(15, 400, read_len=(100, 151)), 150
     want = [oracle.fast_merge(*p) for p in pairs]
-    got = fast_merge_batch(ix, [SequenceReadPair((p[0], p[1]), (p[2], p[3])) for p in pairs])
-    assert got[0] is not None and got[0].seq.decode() == ref["merged_seq"]
+    got, _ = _device_merge(ix, pairs, hint)
+    assert got[0] is not None and got[0][0].decode() == ref["merged_seq"]
     n_merged = 0
     for k, (w, m) in enumerate(zip(want, got)):
-        if w is None:
-            assert m is None, k
-        else:
-            assert m is not None and (m.seq, m.quality, m.diff) == w, k
-            n_merged += 1
-    assert 1000 < n_merged < len(pairs)
-    # one pair through the host entry point
-    for k in (0, 5, 14, 27):
+        assert m == w, (case, k, pairs[k])
+        n_merged += w is not None
+    assert len(pairs) // 5 < n_merged < len(pairs)
+    ix.close()
+
+
+@pytest.mark.gpu
+def test_fast_merge_into_mapping(gpu_device, oracle):
+    """Merged reads come out in the layout gf_map_reads_device takes and map like the
+    oracle's merged strings; the one-pair host entry point and the empty batch."""
+    import torch
+    from genefuserust_amd import Indexer
+    from genefuserust_amd.read_pair import SequenceReadPair, fast_merge_batch
+    g = json.load(open(GOLDEN))
+    genes = [None if x is None else x.encode() for x in g["genes"]]
+    ix = Indexer.from_gene_slices(genes, g["reversed"])
+    ix.make_index()
+    rng = np.random.default_rng(33)
+    g0, g1 = genes[0], genes[1]
+    pairs = []
+    for k in range(300):
+        p, q = int(rng.integers(300, 2600)), int(rng.integers(300, 2200))
+        frag = (g0[p - 130:p] + g1[q:q + 130]) if k % 2 else rand_seq(rng, 260)
+        f = frag[int(rng.integers(0, 30)):][:int(rng.integers(170, 230))]
+        pairs.append((f[:150], b"F" * 150, rc(f)[:150], b"F" * 150))
+    want = [oracle.fast_merge(*p) for p in pairs]
+    got, (bases, off) = _device_merge(ix, pairs, 150)
+    assert got == want
+    lens = (off[1:] - off[:-1])
+    counts, matches = ix.map_reads_device(bases, off, int(lens.max()))
+    torch.cuda.synchronize()
+    ox = oracle.OracleIndexer(genes)
+    cn = counts.cpu().numpy()
+    n_hit = 0
+    for k, w in enumerate(want):
+        exp = 0 if w is None else len(ox.map_read(w[0]))
+        assert int(cn[k]) == exp, k
+        n_hit += exp > 0
+    assert n_hit >= 50
+    for k in (0, 1, 2, 3, 4, 5):
         p = pairs[k]
         one = SequenceReadPair((p[0], p[1]), (p[2], p[3])).fast_merge(ix)
         assert (None if one is None else tuple(one)) == want[k]
-    # empty batch and the device form's layout (offsets are the prefix sum of merged lengths)
     assert fast_merge_batch(ix, []) == []
-    dev = torch.device("cuda", gpu_device)
-    lb, lo = pack_reads([p[0] for p in pairs]); lq, _ = pack_reads([p[1] for p in pairs])
-    rb, ro = pack_reads([p[2] for p in pairs]); rq, _ = pack_reads([p[3] for p in pairs])
-    t = [torch.from_numpy(a).to(dev) for a in (lb, lq, lo, rb, rq, ro)]
-    bases, quals, off, diff = fast_merge_device(ix, *t)
-    lens = (off[1:] - off[:-1]).cpu().numpy()
-    assert [int(x) for x in lens] == [0 if w is None else len(w[0]) for w in want]
-    assert bases.numel() == int(lens.sum()) == quals.numel()
-    # merged reads go straight into the mapping kernel: same hits as mapping the oracle's strings
-    counts, matches = ix.map_reads_device(bases, off, int(lens.max()))
-    torch.cuda.synchronize()
-    ox = oracle.OracleIndexer([None if x is None else x.encode() for x in g["genes"]])
-    cn = counts.cpu().numpy()
-    for k in range(0, len(pairs), 97):
-        w = want[k]
-        assert int(cn[k]) == (0 if w is None else len(ox.map_read(w[0])))
     ix.close()
 
 
