@@ -65,7 +65,8 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="first pass: 0 flat pipeline (default), 1 wave-per-read probe-all, 2 wave-per-read seed+verify")
+    ap.add_argument("--variant", type=int, default=0, help="first pass: 0 flat pipeline (default), 1 wave-per-read probe-all, 2 wave-per-read seed+verify, "
+                    "3 flat pipeline with a separate pack kernel")
     args = ap.parse_args()
 
     import numpy as np
@@ -150,7 +151,7 @@ def main() -> None:
     # per-kernel durations of the flat pipeline (HIP events inside the library, launch stream),
     # taken on extra steps outside the timed region
     stage_ms = None
-    if args.variant == 0:
+    if args.variant in (0, 3):
         ix.set_profiling(True)
         acc = [0.0, 0.0, 0.0, 0.0]
         reps = 5
@@ -159,8 +160,9 @@ def main() -> None:
             ms = ix.last_stage_ms()
             acc = [a + b for a, b in zip(acc, ms)]
         ix.set_profiling(False)
-        stage_ms = dict(zip(["gf_k_pack", "gf_k_seedverify", "gf_k_probe", "gf_k_map_reads_list"],
-                            [round(a / reps, 4) for a in acc]))
+        names = (["gf_k_pack", "gf_k_seedverify", "gf_k_probe", "gf_k_map_reads_list"] if args.variant == 3 else
+                 [None, "gf_k_seedverify_fused", "gf_k_probe_fused", "gf_k_map_reads_list"])
+        stage_ms = {k: round(a / reps, 4) for k, a in zip(names, acc) if k}
 
     total_reads = n * world * args.steps
     value = total_reads / elapsed
@@ -211,10 +213,12 @@ def main() -> None:
                 traffic = None
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": ["gf_map_reads_device = 4 kernels: gf_k_pack + gf_k_seedverify + gf_k_probe + "
-                       "gf_k_map_reads_list (dominant: gf_k_probe); achieved uses their summed duration",
+            "kernel": ["gf_map_reads_device = 3 kernels: gf_k_seedverify_fused + gf_k_probe_fused + "
+                       "gf_k_map_reads_list; achieved uses their summed duration",
                        "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
-                       "gf_k_map_reads_short<4,1> (wave per read, seed+verify)"][args.variant],
+                       "gf_k_map_reads_short<4,1> (wave per read, seed+verify)",
+                       "gf_map_reads_device = 4 kernels: gf_k_pack + gf_k_seedverify + gf_k_probe + "
+                       "gf_k_map_reads_list; achieved uses their summed duration"][args.variant],
             "stage_ms": stage_ms,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

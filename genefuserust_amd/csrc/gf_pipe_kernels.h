@@ -518,6 +518,351 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
   }
 }
 
+// =====================================================================================
+// Fused form (default): K_pack folded into K_seedverify through LDS.
+//
+// Consecutive reads are consecutive bytes (read r = bases[offsets[r] .. offsets[r+1])), so
+// the next <= 256 reads of a block are one contiguous span.  The block converts that span
+// to the packed form with coalesced 16-byte loads straight into LDS, and each thread cuts
+// its read's words out of LDS.  Compared with the separate K_pack this removes the packed
+// stream's round trip through HBM (1.1 GB written + read per 20 M reads) and, more
+// important, ~17 dword gathers per read from it: those were L2 hits, but every one of them
+// is a request against the ~270 G/s L2 ceiling that the presence filter also lives on.
+// An undecided read's packed words travel to K_probe inside its list entry.
+template <int PW>
+struct GfPipeEntryW {  // 64 B (PW = 10) / 96 B (PW = 16)
+  uint32_t read;       // read index in the batch
+  uint32_t v1v2;       // v1 | v2 << 8
+  uint32_t todo[4];    // bit w = stride-2 window w is clean and not verified: probe it
+  uint32_t pk[PW + (PW % 4 == 2 ? 0 : 2)];  // the read's 2-bit codes, 16 bases per word
+};
+
+template <int PW>
+__device__ __forceinline__ void gf_load_read_words_lds(const uint32_t* s_pk, const uint32_t* s_iv, uint32_t pos, int L,
+                                                       uint32_t (&pk)[PW], uint32_t (&iv)[PW]) {
+  constexpr int IW = (PW + 1) / 2;
+  const uint32_t w0 = pos >> 4;
+  const uint32_t sh = 2u * (pos & 15u);
+  uint32_t raw[PW + 1];
+#pragma unroll
+  for (int j = 0; j < PW + 1; ++j) raw[j] = s_pk[w0 + j];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) pk[j] = __builtin_amdgcn_alignbit(raw[j + 1], raw[j], sh);
+  const uint32_t v0 = pos >> 5;
+  const uint32_t vs = pos & 31u;
+  uint32_t rv[IW + 1];
+#pragma unroll
+  for (int j = 0; j < IW + 1; ++j) rv[j] = s_iv[v0 + j];
+#pragma unroll
+  for (int j = 0; j < IW; ++j) {
+    uint32_t b = __builtin_amdgcn_alignbit(rv[j + 1], rv[j], vs);
+    const int k = L - 32 * j;  // bases at or beyond the end of the read are unusable
+    if (k < 32) b |= k <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << k);
+    iv[2 * j] = gf_spread16(b);
+    if (2 * j + 1 < PW) iv[2 * j + 1] = gf_spread16(b >> 16);
+  }
+}
+
+template <int PW>
+__global__ __launch_bounds__(256) void gf_k_seedverify_fused(GfTable T, const uint8_t* __restrict__ bases,
+                                                             const int64_t* __restrict__ offsets, int64_t n, int lmax,
+                                                             int mark_too_long, uint8_t* __restrict__ counts,
+                                                             GfPipeEntryW<PW>* __restrict__ list_b,
+                                                             unsigned int* __restrict__ blk_cnt, int64_t per_block,
+                                                             unsigned int* __restrict__ ctr) {
+  constexpr int TILE_BYTES = 256 * 16 * PW;        // ASCII bytes staged per tile (256 reads of 16*PW bases)
+  constexpr int TILE_CHUNKS = TILE_BYTES / 16 + 1;  // +1: the span starts at a 16-byte boundary at or below its first read
+  __shared__ uint32_t s_pk[TILE_CHUNKS + PW + 2];
+  __shared__ uint32_t s_iv[(TILE_CHUNKS + PW + 2) / 2 + 2];
+  __shared__ unsigned int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  const int64_t r_lo = (int64_t)blockIdx.x * per_block;
+  const int64_t r_hi = r_lo + per_block < n ? r_lo + per_block : n;
+  GfPipeEntryW<PW>* my_list = list_b + r_lo;
+  int64_t r0 = r_lo;
+  while (r0 < r_hi) {
+    // the reads r0 .. r0+nfit-1 (a prefix of the next 256) fit in the tile
+    const uintptr_t a0 = (uintptr_t)(bases + offsets[r0]) & ~(uintptr_t)15;
+    const int64_t r = r0 + threadIdx.x;
+    int64_t off0 = 0, off1 = 0;
+    if (r < r_hi) {
+      off0 = offsets[r];
+      off1 = offsets[r + 1];
+    }
+    const bool fits = r < r_hi && (uintptr_t)(bases + off1) - a0 <= (uintptr_t)TILE_BYTES;
+    int nfit = __syncthreads_count(fits);  // also orders the previous tile's LDS reads before this tile's writes
+    const bool oversize = nfit == 0;       // a single read larger than the tile: far beyond lmax, nothing to stage
+    if (oversize) nfit = 1;
+    if (!oversize) {
+      const uintptr_t span_end = (uintptr_t)(bases + offsets[r0 + nfit]);
+      const uint32_t chunks = (uint32_t)((span_end - a0 + 15) >> 4);
+      for (uint32_t c = threadIdx.x; c < chunks; c += 256) {
+        const uint4 q = *(const uint4*)(a0 + 16 * (uintptr_t)c);
+        uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
+        gf_convert4_bits(q.x, c0, b0);
+        gf_convert4_bits(q.y, c1, b1);
+        gf_convert4_bits(q.z, c2, b2);
+        gf_convert4_bits(q.w, c3, b3);
+        s_pk[c] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        ((uint16_t*)s_iv)[c] = (uint16_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12));
+      }
+    }
+    __syncthreads();
+    const bool in_range = (int)threadIdx.x < nfit;
+    bool undecided = false;
+    uint32_t e_v1v2 = 0, e_todo[4] = {0, 0, 0, 0};
+    uint32_t pk[PW], iv[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) pk[j] = 0;
+    if (in_range) {
+      const int64_t len64 = off1 - off0;
+      if (len64 > lmax) {
+        if (mark_too_long) counts[r] = GF_COUNT_TOO_LONG;  // else: a longer class owns this read
+      } else if (len64 < GF_KMER + 2 * (GF_MAJOR_KEYS / 2 - 1)) {
+        counts[r] = 0;  // fewer than 20 stride-2 windows: count1 < 20 whatever they hit
+      } else {
+        const int L = (int)len64;
+        gf_load_read_words_lds<PW>(s_pk, s_iv, (uint32_t)((uintptr_t)(bases + off0) - a0), L, pk, iv);
+        // clean stride-2 windows of the read (all 16 bases usable): bit 4t of word j = window 8j+t
+        uint32_t cw[PW];
+        gf_clean_windows<PW>(iv, cw);
+        int nvalid = 0;
+#pragma unroll
+        for (int j = 0; j < PW; ++j) nvalid += __popc(cw[j] & 0x11111111u);
+        // seeds at bases 0, 32, 64, 96 (word aligned: the key is one word).  All four go
+        // through the presence filter together (L2 hits).
+        uint32_t cand[4] = {GF_NONE_LIN, GF_NONE_LIN, GF_NONE_LIN, GF_NONE_LIN};
+        {
+          uint32_t key[4];
+          bool ok[4];
+          uint32_t fw[4], fb[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int wj = 2 * s < PW ? 2 * s : 0;
+            key[s] = pk[wj];
+            ok[s] = (2 * s < PW) && (cw[wj] & 1u);
+            if (T.bloom_in_l2) {
+              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[s] >> 4));  // the window's last 14 bases
+              fb[s] = GF_BLOOM_BITS(h2);
+              fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // unconditional: always in range
+            }
+          }
+          if (T.bloom_in_l2) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ok[s] = ok[s] && (fw[s] & fb[s]) == fb[s];
+          }
+          // one bucket probe at a time, in seed order, until one names a diagonal: an
+          // on-target read costs one L2-missing request here, not two
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            bool have = false;
+#pragma unroll
+            for (int s2 = 0; s2 < s; ++s2) have = have || cand[s2] != GF_NONE_LIN;
+            if (ok[s] && !have) {
+              const uint32_t val = gf_lookup(T, key[s]);
+              if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) cand[s] = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
+            }
+          }
+        }
+        // verify each distinct candidate diagonal
+        int v1 = 0, v2 = 0, nver = 0;
+        uint32_t vm[PW];  // verified windows, same sparse layout as cw
+#pragma unroll
+        for (int j = 0; j < PW; ++j) vm[j] = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bool fresh = cand[s] != GF_NONE_LIN;
+#pragma unroll
+          for (int s2 = 0; s2 < s; ++s2) fresh = fresh && cand[s2] != cand[s];
+          if (fresh) {
+            const uint32_t K = cand[s];
+            const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
+            const uint32_t bo = 2u * (K & 15u);
+            uint32_t gdr[PW + 1], ubr[PW + 1];
+#pragma unroll
+            for (int j = 0; j < PW + 1; ++j) {
+              const uint2 v = gp[j];
+              gdr[j] = v.x;
+              ubr[j] = v.y;
+            }
+            uint32_t zz[PW], cl[PW];
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+              const uint32_t g = __builtin_amdgcn_alignbit(gdr[j + 1], gdr[j], bo);
+              const uint32_t x = pk[j] ^ g;
+              zz[j] = ((x | (x >> 1)) & 0x55555555u) | iv[j];  // mismatching or unusable base
+            }
+            gf_clean_windows<PW>(zz, cl);
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+              const uint32_t u = __builtin_amdgcn_alignbit(ubr[j + 1], ubr[j], bo);
+              const uint32_t ver = cl[j] & u & 0x11111111u & ~vm[j];
+              vm[j] |= ver;
+              cnt += __popc(ver);
+            }
+            nver += cnt;
+            if (cnt > v1) { v2 = v1; v1 = cnt; } else if (cnt > v2) { v2 = cnt; }
+          }
+        }
+        // every other diagonal gets at most one vote per window that can still vote
+        const int open = nvalid - nver;
+        if (v1 + open < GF_MAJOR_KEYS / 2 || v2 + open < GF_MINOR_KEYS / 2) {
+          counts[r] = 0;
+        } else {
+          undecided = true;
+          e_v1v2 = (uint32_t)v1 | ((uint32_t)v2 << 8);
+#pragma unroll
+          for (int j = 0; j < PW; ++j)
+            e_todo[j >> 2] |= gf_gather_nibble_lsb(cw[j] & ~vm[j]) << (8 * (j & 3));
+        }
+      }
+    }
+    const unsigned int slot_b = gf_wave_append_lds(undecided, &s_cnt);
+    if (undecided) {
+      // 16-byte stores: the entry is a multiple of 16 bytes and 16-byte aligned
+      uint4* dst = (uint4*)(my_list + slot_b);
+      dst[0] = make_uint4((uint32_t)r, e_v1v2, e_todo[0], e_todo[1]);
+      dst[1] = make_uint4(e_todo[2], e_todo[3], pk[0], pk[1]);
+#pragma unroll
+      for (int j = 2; j + 3 < PW; j += 4) dst[(j + 6) / 4] = make_uint4(pk[j], pk[j + 1], pk[j + 2], pk[j + 3]);
+      if (PW % 4 == 0) dst[(PW + 4) / 4] = make_uint4(pk[PW - 2], pk[PW - 1], 0u, 0u);
+    }
+    r0 += nfit;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt;
+}
+
+// ---- K_probe over the fused kernel's entries: the read's codes come with the entry ----
+template <int PW>
+__global__ __launch_bounds__(256) void gf_k_probe_fused(GfTable T, const GfPipeEntryW<PW>* __restrict__ list_b,
+                                                        const unsigned int* __restrict__ blk_cnt, int64_t per_block,
+                                                        uint8_t* __restrict__ counts, uint32_t* __restrict__ list_c,
+                                                        unsigned int* __restrict__ ctr) {
+  // the read's codes live in LDS for the duration of its probes ([word][thread]: each
+  // thread reads only its own column, conflict-free)
+  __shared__ uint32_t s_pk[(PW + 1) * 256];
+  const unsigned int nb = blk_cnt[blockIdx.x];
+  const GfPipeEntryW<PW>* my_list = list_b + (int64_t)blockIdx.x * per_block;
+  const unsigned int nb_round = (nb + 63u) & ~63u;  // whole waves stay in the loop for the ballot
+  for (unsigned int t = threadIdx.x; t < nb_round; t += blockDim.x) {
+    bool to_full = false;
+    uint32_t r = 0;
+    if (t < nb) {
+      constexpr int EW = sizeof(GfPipeEntryW<PW>) / 16;
+      uint4 ew[EW];
+      const uint4* src = (const uint4*)(my_list + t);
+#pragma unroll
+      for (int j = 0; j < EW; ++j) ew[j] = src[j];
+      r = ew[0].x;
+      const int v1 = (int)(ew[0].y & 0xFFu), v2 = (int)((ew[0].y >> 8) & 0xFFu);
+      uint32_t m0 = ew[0].z, m1 = ew[0].w, m2 = ew[1].x, m3 = ew[1].y;
+      int left = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+      int h = 0;
+      uint32_t pk[PW + 1];
+      pk[0] = ew[1].z;
+      pk[1] = ew[1].w;
+#pragma unroll
+      for (int j = 2; j < PW; ++j) {
+        const uint4 q = ew[(j + 6) / 4];
+        const int k = (j + 6) % 4;
+        pk[j] = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
+      }
+      pk[PW] = 0;
+#pragma unroll
+      for (int j = 0; j <= PW; ++j) s_pk[j * 256 + threadIdx.x] = pk[j];  // phase 2 indexes the words dynamically
+      // phase 1: presence filter over every unverified window, two windows per look-up
+      uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // windows the filter could not rule out
+      bool dead = false;
+      if (T.bloom_words) {
+        const uint32_t td[4] = {m0, m1, m2, m3};
+        uint32_t pp[4] = {0, 0, 0, 0};
+        int npos = 0, rem = left;  // not ruled out so far / not asked yet
+#pragma unroll
+        for (int q0 = 0; q0 < 4 * PW; q0 += 4) {
+          if (!dead) {
+            uint32_t word[4], bits[4], both[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int q = q0 + u;
+              const int wbit = (2 * q) & 31, wword = (2 * q) >> 5;
+              both[u] = wword < 4 ? (td[wword] >> wbit) & 3u : 0u;
+              const int b0 = 4 * q + 2;  // first base of the shared 14-mer
+              const int j = b0 >> 4;
+              const uint32_t sh14 = 2u * (uint32_t)(b0 & 15);
+              const uint32_t s14 = ((pk[j] >> sh14) | (pk[j + 1] << (32u - sh14))) & 0x0FFFFFFFu;  // sh14 is never 0
+              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(s14));
+              bits[u] = GF_BLOOM_BITS(h2);
+              word[u] = 0;
+              if (both[u]) word[u] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int q = q0 + u;
+              const int cnt = (int)(both[u] & 1u) + (int)(both[u] >> 1);
+              rem -= cnt;
+              if (both[u] && (word[u] & bits[u]) == bits[u]) {
+                pp[(2 * q) >> 5 < 4 ? (2 * q) >> 5 : 0] |= both[u] << ((2 * q) & 31);
+                npos += cnt;
+              }
+            }
+            // even if every window not asked yet could vote, the gate is out of reach
+            dead = (v1 + npos + rem < GF_MAJOR_KEYS / 2) || (v2 + npos + rem < GF_MINOR_KEYS / 2);
+          }
+        }
+        p0 = pp[0]; p1 = pp[1]; p2 = pp[2]; p3 = pp[3];
+      } else {
+        p0 = m0; p1 = m1; p2 = m2; p3 = m3;
+      }
+      left = __popc(p0) + __popc(p1) + __popc(p2) + __popc(p3);
+      // phase 2: the exact bucket probe of the remaining windows, stopping as soon as
+      // v1 + h + left < 20 or v2 + h + left < 10
+      dead = dead || (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
+      while (!dead && left > 0) {
+        // the read dies only after at least `need` more probes miss: issue that many (up to
+        // 4) bucket probes together instead of one round trip each
+        const int needA = v1 + h + left - (GF_MAJOR_KEYS / 2 - 1);
+        const int needB = v2 + h + left - (GF_MINOR_KEYS / 2 - 1);
+        int need = needA < needB ? needA : needB;
+        need = need < 1 ? 1 : (need > 4 ? 4 : need);
+        uint32_t key[4];
+        bool act[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          act[u] = u < need && (p0 | p1 | p2 | p3);
+          int w = 0;
+          if (act[u]) {
+            if (p0) { w = __builtin_ctz(p0); p0 &= p0 - 1; }
+            else if (p1) { w = 32 + __builtin_ctz(p1); p1 &= p1 - 1; }
+            else if (p2) { w = 64 + __builtin_ctz(p2); p2 &= p2 - 1; }
+            else { w = 96 + __builtin_ctz(p3); p3 &= p3 - 1; }
+          }
+          const int j = w >> 3;
+          const uint32_t sh = 4u * (uint32_t)(w & 7);
+          key[u] = __builtin_amdgcn_alignbit(s_pk[(j + 1) * 256 + threadIdx.x], s_pk[j * 256 + threadIdx.x], sh);
+        }
+        uint32_t ty[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (act[u]) ty[u] = gf_lookup<GF_PROBE_NT>(T, key[u]) >> GF_TYPE_SHIFT;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (act[u]) {
+            h += (ty[u] == GF_TYPE_UNIQUE || ty[u] == GF_TYPE_DUPES) ? 1 : 0;
+            left -= 1;
+          }
+        }
+        dead = (v1 + h + left < GF_MAJOR_KEYS / 2) || (v2 + h + left < GF_MINOR_KEYS / 2);
+      }
+      if (dead) counts[r] = 0;
+      else to_full = true;
+    }
+    const unsigned int slot = gf_wave_append(to_full, ctr + 1);
+    if (to_full) list_c[slot] = r;
+  }
+}
+
 // ---- K_full: the exact wave-per-read kernel over a list of read indices ----
 template <int LCAP, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 8) void gf_k_map_reads_list(GfTable T, const uint8_t* __restrict__ bases,

@@ -234,10 +234,11 @@ int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, in
 int gf_set_profiling(gf_index* idx, int32_t on);
 
 /* First pass for reads <= 256 bases: 0 (default) = flat pipeline (thread per read:
- * pack, seed + verify, probe the undecided, exact wave-per-read kernel on the
- * survivors), 1 = wave-per-read kernel probing every window, 2 = wave-per-read
- * kernel with seed + verify.  All three are exact and return identical results;
- * the switch exists for A/B timing and for the tests that check exactly that. */
+ * pack + seed + verify in one kernel, probe the undecided, exact wave-per-read kernel
+ * on the survivors), 1 = wave-per-read kernel probing every window, 2 = wave-per-read
+ * kernel with seed + verify, 3 = the flat pipeline with packing as a separate kernel.
+ * All are exact and return identical results; the switch exists for A/B timing and
+ * for the tests that check exactly that. */
 int gf_set_map_variant(gf_index* idx, int32_t variant);
 float gf_last_map_kernel_ms(gf_index* idx);
 

@@ -80,9 +80,10 @@ def test_index_content_every_key(branch_index, golden):
     assert not cnt.any()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_map_golden_cases(branch_index, golden, variant):
-    """variant 0 = flat pipeline, 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify."""
+    """variant 0 = flat pipeline (pack fused into seed+verify), 1 = wave-per-read probe-all,
+    2 = wave-per-read seed+verify, 3 = flat pipeline with a separate pack kernel."""
     branch_index.set_map_variant(variant)
     reads = [c["read"].encode() for c in golden["cases"]]
     got = branch_index.map_reads(reads)
@@ -219,7 +220,7 @@ def test_with_loaded_ref_constructor(gpu_device, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, "0-nofilter", "0-bigfilter"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, "0-nofilter", "0-bigfilter"])
 @pytest.mark.parametrize("shape,scale,n_reads", [("IDX-T", 0.02, 60000), ("IDX-C", 0.004, 60000)])
 def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, variant, monkeypatch):
     """Repeat-rich synthetic genes (2 % repeat family, N bases) and a junction-heavy
@@ -343,7 +344,7 @@ def test_full_size_properties(gpu_device, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 2, 3])
 def test_batches_with_gaps_and_mixed_lengths(branch_index, golden, oracle, variant):
     """Reads need not be packed back to back: gaps between reads (so that most of the
     batch lies beyond the packed stream of the flat pipeline), a first offset > 0, every
@@ -415,6 +416,35 @@ def test_device_offsets_with_holes(branch_index, golden):
     for k, (g, w, ln) in enumerate(zip(got, want, lens)):
         if ln <= 256:
             assert g == w, k
+
+
+@pytest.mark.parametrize("max_read_len", [160, 256])
+def test_read_larger_than_a_staging_tile(branch_index, golden, max_read_len):
+    """The fused seed+verify kernel stages the next reads' bytes in LDS tile by tile; a read
+    larger than a whole tile (40 KB / 64 KB) must be stepped over without staging, and the
+    reads around it keep their answers."""
+    import torch
+    from tests.helpers import matches_to_tuples
+    cases = [c for c in golden["cases"] if len(c["read"]) <= max_read_len]
+    reads = [c["read"].encode() for c in cases]
+    want = [[tuple(m) for m in c["expect"]] for c in cases]
+    giant = (b"ACGTTGCA" * 9000)[:70001]
+    batch = reads[:70] + [giant] + reads[70:] + [giant, giant] + reads[:5]
+    want = want[:70] + [None] + want[70:] + [None, None] + want[:5]
+    offs = np.zeros(len(batch) + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in batch], out=offs[1:])
+    d_b = torch.from_numpy(np.frombuffer(b"".join(batch), dtype=np.uint8).copy()).cuda()
+    d_o = torch.from_numpy(offs).cuda()
+    counts, matches = branch_index.map_reads_device(d_b, d_o, max_read_len)
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy().astype(np.int32)
+    m = matches.cpu().numpy().view(np.dtype([("seq_start", "<i4"), ("seq_end", "<i4"), ("position", "<i4"),
+                                            ("contig", "<i2"), ("pad", "<i2")])).reshape(-1, 2)
+    for k, w in enumerate(want):
+        if w is None:
+            assert c[k] == 255, k
+        else:
+            assert matches_to_tuples(c[k:k + 1], m[k:k + 1]) == [w], k
 
 
 def test_single_read_calls_are_stable(branch_index, golden):
