@@ -218,7 +218,7 @@ def main() -> None:
                        "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
                        "gf_k_map_reads_short<4,1> (wave per read, seed+verify)",
                        "gf_map_reads_device = 4 kernels: gf_k_pack + gf_k_seedverify + gf_k_probe + "
-                       "gf_k_map_reads_list; achieved uses their summed duration"][args.variant],
+                       "gf_k_map_reads_list; achieved uses their summed duration", "fused, register-resident (A/B)"][args.variant],
             "stage_ms": stage_ms,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

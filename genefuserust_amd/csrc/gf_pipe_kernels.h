@@ -563,40 +563,53 @@ __device__ __forceinline__ void gf_load_read_words_lds(const uint32_t* s_pk, con
   }
 }
 
+#ifndef GF_SV_WAVES_PER_SIMD
+#define GF_SV_WAVES_PER_SIMD 4
+#endif
 template <int PW>
-__global__ __launch_bounds__(256) void gf_k_seedverify_fused(GfTable T, const uint8_t* __restrict__ bases,
-                                                             const int64_t* __restrict__ offsets, int64_t n, int lmax,
-                                                             int mark_too_long, uint8_t* __restrict__ counts,
-                                                             GfPipeEntryW<PW>* __restrict__ list_b,
-                                                             unsigned int* __restrict__ blk_cnt, int64_t per_block,
-                                                             unsigned int* __restrict__ ctr) {
-  constexpr int TILE_BYTES = 256 * 16 * PW;        // ASCII bytes staged per tile (256 reads of 16*PW bases)
+__global__ __launch_bounds__(256, PW <= 10 ? GF_SV_WAVES_PER_SIMD : 3) void gf_k_seedverify_fused(
+    GfTable T, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets, int64_t n, int lmax,
+    int mark_too_long, uint8_t* __restrict__ counts, GfPipeEntryW<PW>* __restrict__ list_b,
+    unsigned int* __restrict__ blk_cnt, int64_t per_block, unsigned int* __restrict__ ctr) {
+  // Each wavefront stages and processes its own groups of 64 reads: no block barrier in the
+  // loop, so a wave waiting on its random probes never holds the other three back.
+  constexpr int TILE_BYTES = 64 * 16 * PW;         // ASCII bytes staged per tile (64 reads of 16*PW bases)
   constexpr int TILE_CHUNKS = TILE_BYTES / 16 + 1;  // +1: the span starts at a 16-byte boundary at or below its first read
-  __shared__ uint32_t s_pk[TILE_CHUNKS + PW + 2];
-  __shared__ uint32_t s_iv[(TILE_CHUNKS + PW + 2) / 2 + 2];
+  constexpr int PK_WORDS = TILE_CHUNKS + PW + 2;
+  constexpr int IV_WORDS = (TILE_CHUNKS + PW + 2) / 2 + 2;
+  __shared__ uint32_t s_pk_all[4][PK_WORDS];
+  __shared__ uint32_t s_iv_all[4][IV_WORDS];
   __shared__ unsigned int s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t* s_pk = s_pk_all[wave];
+  uint32_t* s_iv = s_iv_all[wave];
   const int64_t r_lo = (int64_t)blockIdx.x * per_block;
   const int64_t r_hi = r_lo + per_block < n ? r_lo + per_block : n;
   GfPipeEntryW<PW>* my_list = list_b + r_lo;
-  int64_t r0 = r_lo;
-  while (r0 < r_hi) {
-    // the reads r0 .. r0+nfit-1 (a prefix of the next 256) fit in the tile
+  for (int64_t g0 = r_lo + 64 * (int64_t)wave; g0 < r_hi; g0 += 256) {
+   const int64_t g1 = g0 + 64 < r_hi ? g0 + 64 : r_hi;
+   int64_t r0 = g0;
+   while (r0 < g1) {
+    // the reads r0 .. r0+nfit-1 (a prefix of the group) fit in the tile
     const uintptr_t a0 = (uintptr_t)(bases + offsets[r0]) & ~(uintptr_t)15;
-    const int64_t r = r0 + threadIdx.x;
+    const int64_t r = r0 + lane;
     int64_t off0 = 0, off1 = 0;
-    if (r < r_hi) {
+    if (r < g1) {
       off0 = offsets[r];
       off1 = offsets[r + 1];
     }
-    const bool fits = r < r_hi && (uintptr_t)(bases + off1) - a0 <= (uintptr_t)TILE_BYTES;
-    int nfit = __syncthreads_count(fits);  // also orders the previous tile's LDS reads before this tile's writes
-    const bool oversize = nfit == 0;       // a single read larger than the tile: far beyond lmax, nothing to stage
+    const bool fits = r < g1 && (uintptr_t)(bases + off1) - a0 <= (uintptr_t)TILE_BYTES;
+    int nfit = __popcll(__ballot(fits));
+    const bool oversize = nfit == 0;  // a single read larger than the tile: far beyond lmax, nothing to stage
     if (oversize) nfit = 1;
+    gf_wave_lds_sync();  // the previous tile's LDS reads are done
     if (!oversize) {
       const uintptr_t span_end = (uintptr_t)(bases + offsets[r0 + nfit]);
       const uint32_t chunks = (uint32_t)((span_end - a0 + 15) >> 4);
-      for (uint32_t c = threadIdx.x; c < chunks; c += 256) {
+      for (uint32_t c = lane; c < chunks; c += 64) {
         const uint4 q = *(const uint4*)(a0 + 16 * (uintptr_t)c);
         uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
         gf_convert4_bits(q.x, c0, b0);
@@ -607,8 +620,8 @@ __global__ __launch_bounds__(256) void gf_k_seedverify_fused(GfTable T, const ui
         ((uint16_t*)s_iv)[c] = (uint16_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12));
       }
     }
-    __syncthreads();
-    const bool in_range = (int)threadIdx.x < nfit;
+    gf_wave_lds_sync();
+    const bool in_range = lane < nfit;
     bool undecided = false;
     uint32_t e_v1v2 = 0, e_todo[4] = {0, 0, 0, 0};
     uint32_t pk[PW], iv[PW];
@@ -623,6 +636,9 @@ __global__ __launch_bounds__(256) void gf_k_seedverify_fused(GfTable T, const ui
       } else {
         const int L = (int)len64;
         gf_load_read_words_lds<PW>(s_pk, s_iv, (uint32_t)((uintptr_t)(bases + off0) - a0), L, pk, iv);
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 1
+        { uint32_t a = 0; for (int j = 0; j < PW; ++j) a ^= pk[j] ^ iv[j]; counts[r] = (uint8_t)(a == 0x1234567u); }
+#else
         // clean stride-2 windows of the read (all 16 bases usable): bit 4t of word j = window 8j+t
         uint32_t cw[PW];
         gf_clean_windows<PW>(iv, cw);
@@ -631,7 +647,7 @@ __global__ __launch_bounds__(256) void gf_k_seedverify_fused(GfTable T, const ui
         for (int j = 0; j < PW; ++j) nvalid += __popc(cw[j] & 0x11111111u);
         // seeds at bases 0, 32, 64, 96 (word aligned: the key is one word).  All four go
         // through the presence filter together (L2 hits).
-        uint32_t cand[4] = {GF_NONE_LIN, GF_NONE_LIN, GF_NONE_LIN, GF_NONE_LIN};
+        uint32_t K = GF_NONE_LIN;  // candidate diagonal: site code of read base 0
         {
           uint32_t key[4];
           bool ok[4];
@@ -651,59 +667,88 @@ __global__ __launch_bounds__(256) void gf_k_seedverify_fused(GfTable T, const ui
 #pragma unroll
             for (int s = 0; s < 4; ++s) ok[s] = ok[s] && (fw[s] & fb[s]) == fb[s];
           }
-          // one bucket probe at a time, in seed order, until one names a diagonal: an
-          // on-target read costs one L2-missing request here, not two
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 3
+          if (nvalid + ok[0] + 2 * ok[1] + 4 * ok[2] + 8 * ok[3] == 0x1234567) counts[r] = 1;
+          ok[0] = ok[1] = ok[2] = ok[3] = false;
+#endif
+          // Round 1: every read probes the first of its seeds that passed the filter — an
+          // on-target read is done here with one L2-missing request.  Round 2: the reads still
+          // without a diagonal probe all their remaining seeds together.  (A wave runs every
+          // round any of its lanes needs: two rounds, not one per seed.)
+          uint32_t okm = (ok[0] ? 1u : 0u) | (ok[1] ? 2u : 0u) | (ok[2] ? 4u : 0u) | (ok[3] ? 8u : 0u);
+          if (okm) {
+            const int s1 = __builtin_ctz(okm);
+            okm &= okm - 1;
+            const uint32_t k1 = s1 == 0 ? key[0] : (s1 == 1 ? key[1] : (s1 == 2 ? key[2] : key[3]));
+            const uint32_t val = gf_lookup(T, k1);
+            if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s1;
+          }
+#ifndef GF_SV_R2
+#define GF_SV_R2 3  // seeds probed together in round 2
+#endif
+          if (K == GF_NONE_LIN && okm) {
+            uint4 q[GF_SV_R2][4];
+            bool act[GF_SV_R2];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            bool have = false;
+            for (int s = 1; s <= GF_SV_R2; ++s) {
+              act[s - 1] = (okm >> s) & 1u;
+              if (act[s - 1]) {
+                const uint4* p = (const uint4*)(T.slots + (size_t)gf_bucket_of(key[s], T.nbuckets) * GF_SLOTS_PER_BUCKET);
+                q[s - 1][0] = p[0]; q[s - 1][1] = p[1]; q[s - 1][2] = p[2]; q[s - 1][3] = p[3];
+              }
+            }
 #pragma unroll
-            for (int s2 = 0; s2 < s; ++s2) have = have || cand[s2] != GF_NONE_LIN;
-            if (ok[s] && !have) {
-              const uint32_t val = gf_lookup(T, key[s]);
-              if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) cand[s] = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
+            for (int s = 1; s <= GF_SV_R2; ++s) {
+              if (act[s - 1] && K == GF_NONE_LIN) {
+                bool ovf;
+                uint32_t val = gf_match_bucket(q[s - 1][0], q[s - 1][1], q[s - 1][2], q[s - 1][3], key[s], ovf);
+                if (ovf) val = gf_lookup(T, key[s]);  // the key may sit in a later bucket (2 % of buckets)
+                if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
+              }
+            }
+#pragma unroll
+            for (int s = GF_SV_R2 + 1; s < 4; ++s) {
+              if (((okm >> s) & 1u) && K == GF_NONE_LIN) {
+                const uint32_t val = gf_lookup(T, key[s]);
+                if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
+              }
             }
           }
         }
-        // verify each distinct candidate diagonal
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 4
+        if (K == 0x1234567u) counts[r] = 1;
+        K = GF_NONE_LIN;
+#endif
+        // verify the candidate diagonal
         int v1 = 0, v2 = 0, nver = 0;
         uint32_t vm[PW];  // verified windows, same sparse layout as cw
 #pragma unroll
         for (int j = 0; j < PW; ++j) vm[j] = 0;
+        if (K != GF_NONE_LIN) {
+          const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
+          const uint32_t bo = 2u * (K & 15u);
+          uint32_t gdr[PW + 1], ubr[PW + 1];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          bool fresh = cand[s] != GF_NONE_LIN;
-#pragma unroll
-          for (int s2 = 0; s2 < s; ++s2) fresh = fresh && cand[s2] != cand[s];
-          if (fresh) {
-            const uint32_t K = cand[s];
-            const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
-            const uint32_t bo = 2u * (K & 15u);
-            uint32_t gdr[PW + 1], ubr[PW + 1];
-#pragma unroll
-            for (int j = 0; j < PW + 1; ++j) {
-              const uint2 v = gp[j];
-              gdr[j] = v.x;
-              ubr[j] = v.y;
-            }
-            uint32_t zz[PW], cl[PW];
-#pragma unroll
-            for (int j = 0; j < PW; ++j) {
-              const uint32_t g = __builtin_amdgcn_alignbit(gdr[j + 1], gdr[j], bo);
-              const uint32_t x = pk[j] ^ g;
-              zz[j] = ((x | (x >> 1)) & 0x55555555u) | iv[j];  // mismatching or unusable base
-            }
-            gf_clean_windows<PW>(zz, cl);
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < PW; ++j) {
-              const uint32_t u = __builtin_amdgcn_alignbit(ubr[j + 1], ubr[j], bo);
-              const uint32_t ver = cl[j] & u & 0x11111111u & ~vm[j];
-              vm[j] |= ver;
-              cnt += __popc(ver);
-            }
-            nver += cnt;
-            if (cnt > v1) { v2 = v1; v1 = cnt; } else if (cnt > v2) { v2 = cnt; }
+          for (int j = 0; j < PW + 1; ++j) {
+            const uint2 v = gp[j];
+            gdr[j] = v.x;
+            ubr[j] = v.y;
           }
+          uint32_t zz[PW], cl[PW];
+#pragma unroll
+          for (int j = 0; j < PW; ++j) {
+            const uint32_t g = __builtin_amdgcn_alignbit(gdr[j + 1], gdr[j], bo);
+            const uint32_t x = pk[j] ^ g;
+            zz[j] = ((x | (x >> 1)) & 0x55555555u) | iv[j];  // mismatching or unusable base
+          }
+          gf_clean_windows<PW>(zz, cl);
+#pragma unroll
+          for (int j = 0; j < PW; ++j) {
+            const uint32_t u = __builtin_amdgcn_alignbit(ubr[j + 1], ubr[j], bo);
+            vm[j] = cl[j] & u & 0x11111111u;
+            v1 += __popc(vm[j]);
+          }
+          nver = v1;
         }
         // every other diagonal gets at most one vote per window that can still vote
         const int open = nvalid - nver;
@@ -716,6 +761,7 @@ __global__ __launch_bounds__(256) void gf_k_seedverify_fused(GfTable T, const ui
           for (int j = 0; j < PW; ++j)
             e_todo[j >> 2] |= gf_gather_nibble_lsb(cw[j] & ~vm[j]) << (8 * (j & 3));
         }
+#endif  // GF_ABLATE_SV == 1
       }
     }
     const unsigned int slot_b = gf_wave_append_lds(undecided, &s_cnt);
@@ -729,6 +775,306 @@ __global__ __launch_bounds__(256) void gf_k_seedverify_fused(GfTable T, const ui
       if (PW % 4 == 0) dst[(PW + 4) / 4] = make_uint4(pk[PW - 2], pk[PW - 1], 0u, 0u);
     }
     r0 += nfit;
+   }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt;
+}
+
+// ---- streaming form of the fused kernel (default) ----
+// Same decisions as gf_k_seedverify_fused, but a read's words are never held in registers
+// all at once: they stay in the wave's LDS tile and are cut out word by word wherever they
+// are needed (clean-window bits, seeds, verification, list entry).  The per-lane state is a
+// few rolling words, so twice as many waves fit on a SIMD — and the kernel is bound by how
+// many random probes the CU keeps in flight, not by arithmetic.
+__device__ __forceinline__ uint32_t gf_cut_pk(const uint32_t* s_pk, uint32_t w0, uint32_t sh, int j) {
+  return __builtin_amdgcn_alignbit(s_pk[w0 + j + 1], s_pk[w0 + j], sh);
+}
+
+// unusable-base flags of bases 16j .. 16j+15 of the read, at the even bits (2-bit layout)
+__device__ __forceinline__ uint32_t gf_cut_iv(const uint32_t* s_iv, uint32_t pos, int L, int j) {
+  const uint32_t bp = pos + 16u * (uint32_t)j;
+  uint32_t b = __builtin_amdgcn_alignbit(s_iv[(bp >> 5) + 1], s_iv[bp >> 5], bp & 31u) & 0xFFFFu;
+  const int k = L - 16 * j;  // bases at or beyond the end of the read are unusable
+  if (k < 16) b |= k <= 0 ? 0xFFFFu : ((0xFFFFu << k) & 0xFFFFu);
+  return gf_spread16(b);
+}
+
+// bit 2p set iff bases p .. p+15 are all good, for the 16 bases of the word whose bad-base
+// flags are z_lo; z_hi = the flags of the next word
+__device__ __forceinline__ uint32_t gf_clean16(uint32_t z_lo, uint32_t z_hi) {
+  uint32_t lo = ~z_lo & 0x55555555u, hi = ~z_hi & 0x55555555u;
+#pragma unroll
+  for (uint32_t sh = 2; sh <= 16; sh <<= 1) {
+    lo &= __builtin_amdgcn_alignbit(hi, lo, sh);
+    hi &= hi >> sh;
+  }
+  return lo;
+}
+
+// 16 ASCII bases -> 32 code bits and 16 "not A/C/G/T" bits.  The expected letter of each
+// 2-bit code comes from one v_perm_b32 table lookup; a chunk whose 16 bytes all equal their
+// expected letters (the usual case) is done without looking at single bytes.
+__device__ __forceinline__ void gf_convert16(const uint4& q, uint32_t& code32, uint32_t& bad16) {
+  const uint32_t y0 = (q.x >> 1) & 0x03030303u, y1 = (q.y >> 1) & 0x03030303u;
+  const uint32_t y2 = (q.z >> 1) & 0x03030303u, y3 = (q.w >> 1) & 0x03030303u;
+  // table bytes: code 0 'A', 1 'C', 2 'T', 3 'G'
+  const uint32_t d0 = q.x ^ __builtin_amdgcn_perm(0u, 0x47544341u, y0), d1 = q.y ^ __builtin_amdgcn_perm(0u, 0x47544341u, y1);
+  const uint32_t d2 = q.z ^ __builtin_amdgcn_perm(0u, 0x47544341u, y2), d3 = q.w ^ __builtin_amdgcn_perm(0u, 0x47544341u, y3);
+  code32 = ((y0 * 0x01041040u) >> 24) | (((y1 * 0x01041040u) >> 24) << 8) | (((y2 * 0x01041040u) >> 24) << 16) |
+           (((y3 * 0x01041040u) >> 24) << 24);
+  bad16 = 0;
+  if (d0 | d1 | d2 | d3) {
+    // bit 7 of each byte = that byte differs; gathered to one bit per base
+    const uint32_t n0 = (((d0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d0) & 0x80808080u;
+    const uint32_t n1 = (((d1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d1) & 0x80808080u;
+    const uint32_t n2 = (((d2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d2) & 0x80808080u;
+    const uint32_t n3 = (((d3 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d3) & 0x80808080u;
+    // bits 7,15,23,31 -> bits 0..3
+    bad16 = (((n0 >> 7) * 0x00204081u) >> 21 & 0xFu) | ((((n1 >> 7) * 0x00204081u) >> 21 & 0xFu) << 4) |
+            ((((n2 >> 7) * 0x00204081u) >> 21 & 0xFu) << 8) | ((((n3 >> 7) * 0x00204081u) >> 21 & 0xFu) << 12);
+  }
+}
+
+// windows 32k .. 32k+31 of a read with nwin windows, one bit each
+__device__ __forceinline__ uint32_t gf_window_mask(int nwin, int k) {
+  const int m = nwin - 32 * k;
+  return m >= 32 ? 0xFFFFFFFFu : (m <= 0 ? 0u : ((1u << m) - 1u));
+}
+
+#ifndef GF_SVS_WAVES_PER_SIMD
+#define GF_SVS_WAVES_PER_SIMD 6
+#endif
+template <int PW>
+__global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_k_seedverify_stream(
+    GfTable T, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets, int64_t n, int lmax,
+    int mark_too_long, uint8_t* __restrict__ counts, GfPipeEntryW<PW>* __restrict__ list_b,
+    unsigned int* __restrict__ blk_cnt, int64_t per_block, unsigned int* __restrict__ ctr) {
+  constexpr int TILE_BYTES = 64 * 16 * PW;         // ASCII bytes staged per tile (64 reads of 16*PW bases)
+  constexpr int TILE_CHUNKS = TILE_BYTES / 16 + 1;  // +1: the span starts at a 16-byte boundary at or below its first read
+  constexpr int PK_WORDS = TILE_CHUNKS + PW + 2;
+  constexpr int IV_WORDS = (TILE_CHUNKS + PW + 2) / 2 + 2;
+  constexpr int NLOAD = (TILE_CHUNKS + 63) / 64;    // 16-byte chunks per lane per tile
+  constexpr int IW = (PW + 1) / 2;                  // 32-base words of flag bits per read
+  __shared__ uint32_t s_pk_all[4][PK_WORDS];
+  __shared__ uint32_t s_iv_all[4][IV_WORDS];
+  __shared__ unsigned int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t* s_pk = s_pk_all[wave];
+  uint32_t* s_iv = s_iv_all[wave];
+  const int64_t r_lo = (int64_t)blockIdx.x * per_block;
+  const int64_t r_hi = r_lo + per_block < n ? r_lo + per_block : n;
+  GfPipeEntryW<PW>* my_list = list_b + r_lo;
+  for (int64_t g0 = r_lo + 64 * (int64_t)wave; g0 < r_hi; g0 += 256) {
+    const int64_t g1 = g0 + 64 < r_hi ? g0 + 64 : r_hi;
+    int64_t r0 = g0;
+    while (r0 < g1) {
+      // the reads r0 .. r0+nfit-1 (a prefix of the group) fit in the tile.  The tile starts at
+      // the 16-byte boundary at or below the first read (pointer arithmetic on `bases` keeps
+      // the loads in the global address space with a scalar base).
+      const int64_t base_off = offsets[r0];
+      const uint8_t* p0 = bases + base_off;
+      const uint32_t mis = (uint32_t)((uintptr_t)p0 & 15u);
+      const uint4* src = (const uint4*)(p0 - mis);
+      const int64_t r = r0 + lane;
+      int64_t off0 = 0, off1 = 0;
+      if (r < g1) {
+        off0 = offsets[r];
+        off1 = offsets[r + 1];
+      }
+      const bool fits = r < g1 && (uint64_t)(off1 - base_off) + mis <= (uint64_t)TILE_BYTES;
+      int nfit = __popcll(__ballot(fits));
+      const bool oversize = nfit == 0;  // a single read larger than the tile: far beyond lmax, nothing to stage
+      if (oversize) nfit = 1;
+      gf_wave_lds_sync();  // the previous tile's LDS reads are done
+      const uint32_t chunks = oversize ? 0u : (uint32_t)((offsets[r0 + nfit] - base_off) + mis + 15) >> 4;
+      if (chunks > 0) {  // (empty reads only: nothing to stage)
+        uint4 q[NLOAD];
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {  // all of the tile's loads in flight together
+          const uint32_t c = (uint32_t)lane + 64u * (uint32_t)k;
+#ifndef GF_STAGE_TEMPORAL  // streamed once: keep the bases out of the way of the table and the filter
+          const gf_u32x4 t = __builtin_nontemporal_load((const gf_u32x4*)(src + (c < chunks ? c : chunks - 1)));
+          q[k] = make_uint4(t.x, t.y, t.z, t.w);
+#else
+          q[k] = src[c < chunks ? c : chunks - 1];
+#endif
+        }
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+          const uint32_t c = (uint32_t)lane + 64u * (uint32_t)k;
+          uint32_t code32, bad16;
+          gf_convert16(q[k], code32, bad16);
+          if (c < chunks) {
+            s_pk[c] = code32;
+            ((uint16_t*)s_iv)[c] = (uint16_t)bad16;
+          }
+        }
+      }
+      gf_wave_lds_sync();
+      __builtin_amdgcn_sched_barrier(0);
+      const bool in_range = lane < nfit;
+      bool undecided = false;
+      uint32_t e_v1v2 = 0, e_todo[4] = {0, 0, 0, 0};
+      uint32_t w0 = 0, sh = 0;
+      if (in_range) {
+        const int64_t len64 = off1 - off0;
+        if (len64 > lmax) {
+          if (mark_too_long) counts[r] = GF_COUNT_TOO_LONG;  // else: a longer class owns this read
+        } else if (len64 < GF_KMER + 2 * (GF_MAJOR_KEYS / 2 - 1)) {
+          counts[r] = 0;  // fewer than 20 stride-2 windows: count1 < 20 whatever they hit
+        } else {
+          const int L = (int)len64;
+          const uint32_t pos = (uint32_t)(off0 - base_off) + mis;
+          w0 = pos >> 4;
+          sh = 2u * (pos & 15u);
+          // does the read hold any base outside A/C/G/T?  (flag bits pos .. pos+L-1)
+          uint32_t anybad = 0;
+          {
+            const uint32_t v0 = pos >> 5, vs = pos & 31u;
+            uint32_t lo = s_iv[v0];
+#pragma unroll
+            for (int j = 0; j < IW; ++j) {
+              const uint32_t hi = s_iv[v0 + j + 1];
+              uint32_t b = __builtin_amdgcn_alignbit(hi, lo, vs);
+              const int k = L - 32 * j;
+              if (k < 32) b &= k <= 0 ? 0u : ((1u << k) - 1u);
+              anybad |= b;
+              lo = hi;
+            }
+          }
+          // pass A: the clean stride-2 windows (all 16 bases usable), one bit per window, and
+          // the seeds at bases 0, 32, 64, 96
+          uint32_t cwb[4];
+          int nvalid;
+          uint32_t key[4];
+          uint32_t okm = 0;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) key[s] = 2 * s < PW ? gf_cut_pk(s_pk, w0, sh, 2 * s) : 0u;
+          if (!anybad) {
+            nvalid = (L - GF_KMER) / 2 + 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cwb[k] = gf_window_mask(nvalid, k);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) okm |= (2 * s < PW && 16 * s < nvalid ? 1u : 0u) << s;
+          } else {
+            cwb[0] = cwb[1] = cwb[2] = cwb[3] = 0;
+            nvalid = 0;
+            uint32_t z_cur = gf_cut_iv(s_iv, pos, L, 0);
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+              const uint32_t z_next = j + 1 < PW ? gf_cut_iv(s_iv, pos, L, j + 1) : 0x55555555u;
+              const uint32_t cw = gf_clean16(z_cur, z_next) & 0x11111111u;
+              nvalid += __popc(cw);
+              cwb[j >> 2] |= gf_gather_nibble_lsb(cw) << (8 * (j & 3));
+              if ((j & 1) == 0 && j < 8) okm |= (cw & 1u) << (j >> 1);
+              z_cur = z_next;
+            }
+          }
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 1
+          if ((nvalid ^ key[0] ^ key[1] ^ key[2] ^ key[3] ^ cwb[0] ^ cwb[1] ^ cwb[2] ^ cwb[3] ^ okm) == 0x1234567u) counts[r] = 1;
+          okm = 0;
+#endif
+          // all four seeds go through the presence filter together (L2 hits)
+          if (T.bloom_in_l2) {
+            uint32_t fw[4], fb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[s] >> 4));  // the window's last 14 bases
+              fb[s] = GF_BLOOM_BITS(h2);
+              fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // unconditional: always in range
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              if ((fw[s] & fb[s]) != fb[s]) okm &= ~(1u << s);
+          }
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 3
+          if (okm == 0x1234567u) counts[r] = 1;
+          okm = 0;
+#endif
+          // one bucket probe at a time, in seed order, until one names a diagonal: an
+          // on-target read costs one L2-missing request here
+          uint32_t K = GF_NONE_LIN;  // candidate diagonal: site code of read base 0
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if (((okm >> s) & 1u) && K == GF_NONE_LIN) {
+              const uint32_t val = gf_lookup(T, key[s]);
+              if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
+            }
+          }
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 4
+          if (K == 0x1234567u) counts[r] = 1;
+          K = GF_NONE_LIN;
+#endif
+          // pass B: verify the candidate diagonal against the genes in site-code space, a
+          // word of the read at a time: window w counts iff its 16 bases equal the bases of
+          // site K + 2w and that site is the only site of its key
+          uint32_t vmb[4] = {0, 0, 0, 0};  // verified windows, one bit per window like cwb
+          if (K != GF_NONE_LIN) {
+            const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
+            const uint32_t bo = 2u * (K & 15u);
+            uint2 gw[PW + 1];
+#pragma unroll
+            for (int j = 0; j < PW + 1; ++j) gw[j] = gp[j];
+            uint32_t zz_cur;
+            {
+              const uint32_t x = gf_cut_pk(s_pk, w0, sh, 0) ^ __builtin_amdgcn_alignbit(gw[1].x, gw[0].x, bo);
+              zz_cur = (x | (x >> 1)) & 0x55555555u;  // mismatching base
+              if (anybad) zz_cur |= gf_cut_iv(s_iv, pos, L, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+              uint32_t zz_next = 0x55555555u;
+              if (j + 1 < PW) {
+                const uint32_t x = gf_cut_pk(s_pk, w0, sh, j + 1) ^
+                                   __builtin_amdgcn_alignbit(gw[j + 2 <= PW ? j + 2 : PW].x, gw[j + 1].x, bo);
+                zz_next = (x | (x >> 1)) & 0x55555555u;
+                if (anybad) zz_next |= gf_cut_iv(s_iv, pos, L, j + 1);
+              }
+              const uint32_t u = __builtin_amdgcn_alignbit(gw[j + 1].y, gw[j].y, bo);
+              const uint32_t ver = gf_clean16(zz_cur, zz_next) & u & 0x11111111u;
+              vmb[j >> 2] |= gf_gather_nibble_lsb(ver) << (8 * (j & 3));
+              zz_cur = zz_next;
+              if (j & 1) __builtin_amdgcn_sched_barrier(0);  // keep it a stream: two words in flight
+            }
+          }
+          int v1 = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            vmb[k] &= cwb[k];  // windows that run past the end of the read compared garbage
+            v1 += __popc(vmb[k]);
+          }
+          // every other diagonal gets at most one vote per window that can still vote
+          const int open = nvalid - v1;
+          if (v1 + open < GF_MAJOR_KEYS / 2 || open < GF_MINOR_KEYS / 2) {
+            counts[r] = 0;
+          } else {
+            undecided = true;
+            e_v1v2 = (uint32_t)v1;  // v2 = 0: one candidate diagonal per read
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e_todo[k] = cwb[k] & ~vmb[k];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned int slot_b = gf_wave_append_lds(undecided, &s_cnt);
+      if (undecided) {
+        // 16-byte stores: the entry is a multiple of 16 bytes and 16-byte aligned
+        uint4* dst = (uint4*)(my_list + slot_b);
+        dst[0] = make_uint4((uint32_t)r, e_v1v2, e_todo[0], e_todo[1]);
+        dst[1] = make_uint4(e_todo[2], e_todo[3], gf_cut_pk(s_pk, w0, sh, 0), gf_cut_pk(s_pk, w0, sh, 1));
+#pragma unroll
+        for (int j = 2; j + 3 < PW; j += 4)
+          dst[(j + 6) / 4] = make_uint4(gf_cut_pk(s_pk, w0, sh, j), gf_cut_pk(s_pk, w0, sh, j + 1),
+                                        gf_cut_pk(s_pk, w0, sh, j + 2), gf_cut_pk(s_pk, w0, sh, j + 3));
+        if (PW % 4 == 0)
+          dst[(PW + 4) / 4] = make_uint4(gf_cut_pk(s_pk, w0, sh, PW - 2), gf_cut_pk(s_pk, w0, sh, PW - 1), 0u, 0u);
+      }
+      r0 += nfit;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt;

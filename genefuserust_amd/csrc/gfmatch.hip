@@ -168,7 +168,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
 
   std::unique_ptr<gf_index> ix(new gf_index());
   ix->device = dev;
-  if (const char* e = getenv("GF_MAP_VARIANT")) ix->map_variant = atoi(e) >= 0 && atoi(e) <= 3 ? atoi(e) : 0;  // experiments
+  if (const char* e = getenv("GF_MAP_VARIANT")) ix->map_variant = atoi(e) >= 0 && atoi(e) <= 4 ? atoi(e) : 0;  // experiments
   hipDeviceProp_t prop;
   GF_HIP(hipGetDeviceProperties(&prop, dev));
   ix->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -403,8 +403,10 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
   // each launch skips the reads of the other classes, so short reads always get the
   // small-LDS kernel with the seed+verify first pass.
   const int top = max_read_len <= 256 ? 0 : (max_read_len <= 1024 ? 1 : 2);
-  if (idx->map_variant == 0) {
-    // flat pipeline, K_pack fused into K_seedverify through LDS
+  if (idx->map_variant == 0 || idx->map_variant == 4) {
+    // flat pipeline, K_pack fused into K_seedverify through LDS (4 = the register-resident
+    // form of the fused kernel, kept for A/B timing)
+    const bool streamk = idx->map_variant == 0;
     const bool small = max_read_len <= 160;
     const int lmax = top == 0 ? max_read_len : 256;
     const int mark = top == 0 ? 1 : 0;
@@ -438,15 +440,23 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     }
     if (small) {
       constexpr int PW = 10;  // 16-base words of a read of up to 160 bases
-      hipLaunchKernelGGL((gf_k_seedverify_fused<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
-                         lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
+      if (streamk)
+        hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
+                           lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
+      else
+        hipLaunchKernelGGL((gf_k_seedverify_fused<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
+                           lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
       if (prof) GF_HIP(hipEventRecord(mix->ev_stage[2], st));
       hipLaunchKernelGGL((gf_k_probe_fused<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
                          (const GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, counts, list_c, ctr);
     } else {
       constexpr int PW = 16;  // up to 256 bases
-      hipLaunchKernelGGL((gf_k_seedverify_fused<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
-                         lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
+      if (streamk)
+        hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
+                           lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
+      else
+        hipLaunchKernelGGL((gf_k_seedverify_fused<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
+                           lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
       if (prof) GF_HIP(hipEventRecord(mix->ev_stage[2], st));
       hipLaunchKernelGGL((gf_k_probe_fused<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
                          (const GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, counts, list_c, ctr);
@@ -960,7 +970,7 @@ int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, in
 }
 
 int gf_set_map_variant(gf_index* idx, int32_t variant) {
-  if (!idx || variant < 0 || variant > 3) return fail(GF_ERR_ARG, "bad variant");
+  if (!idx || variant < 0 || variant > 4) return fail(GF_ERR_ARG, "bad variant");
   idx->map_variant = variant;
   return GF_OK;
 }

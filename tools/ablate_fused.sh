@@ -1,0 +1,22 @@
+#!/bin/bash
+# Timing-only builds of the fused seed+verify kernel (ablations give wrong results by
+# construction; occupancy variants are exact).  build here, run on the GPU box.
+#   GF_ABLATE_SV: 1 = stage + cut words only, 3 = + presence filter, 4 = + seed probes (no verification)
+#   GF_SV_WAVES_PER_SIMD: register budget of the kernel
+set -e
+REPO=$(cd $(dirname $0)/.. && pwd)
+VARIANTS="sv1:-DGF_ABLATE_SV=1 sv3:-DGF_ABLATE_SV=3 sv4:-DGF_ABLATE_SV=4 r2:-DGF_SV_R2=2 r1:-DGF_SV_R2=1 w3:-DGF_SV_WAVES_PER_SIMD=3"
+if [ "$1" = build ]; then
+  for v in $VARIANTS; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 ${v#*:} -shared \
+      -o $REPO/genefuserust_amd/libgfmatch_${v%%:*}.so $REPO/genefuserust_amd/csrc/gfmatch.hip &
+  done
+  wait
+else
+  for v in full $VARIANTS; do
+    name=${v%%:*}
+    lib=$REPO/genefuserust_amd/libgfmatch_$name.so; [ $name = full ] && lib=$REPO/genefuserust_amd/libgfmatch.so
+    GFMATCH_LIB=$lib python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity "${@:2}" 2>/dev/null | \
+      python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', d['roofline']['kernel_ms_avg'], d['roofline']['stage_ms'])"
+  done
+fi
