@@ -161,7 +161,7 @@ def main() -> None:
             acc = [a + b for a, b in zip(acc, ms)]
         ix.set_profiling(False)
         names = (["gf_k_pack", "gf_k_seedverify", "gf_k_probe", "gf_k_map_reads_list"] if args.variant == 3 else
-                 [None, "gf_k_seedverify_fused", "gf_k_probe_fused", "gf_k_map_reads_list"])
+                 ["gf_k_seedverify_stream", "gf_k_probe_filter", "gf_k_probe_buckets", "gf_k_map_reads_list"])
         stage_ms = {k: round(a / reps, 4) for k, a in zip(names, acc) if k}
 
     total_reads = n * world * args.steps
@@ -213,12 +213,12 @@ def main() -> None:
                 traffic = None
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": ["gf_map_reads_device = 3 kernels: gf_k_seedverify_fused + gf_k_probe_fused + "
-                       "gf_k_map_reads_list; achieved uses their summed duration",
+            "kernel": ["gf_map_reads_device = 4 kernels: gf_k_seedverify_stream + gf_k_probe_filter + "
+                       "gf_k_probe_buckets + gf_k_map_reads_list; achieved uses their summed duration",
                        "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
                        "gf_k_map_reads_short<4,1> (wave per read, seed+verify)",
                        "gf_map_reads_device = 4 kernels: gf_k_pack + gf_k_seedverify + gf_k_probe + "
-                       "gf_k_map_reads_list; achieved uses their summed duration", "fused, register-resident (A/B)"][args.variant],
+                       "gf_k_map_reads_list; achieved uses their summed duration"][args.variant],
             "stage_ms": stage_ms,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

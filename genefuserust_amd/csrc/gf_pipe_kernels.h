@@ -537,256 +537,11 @@ struct GfPipeEntryW {  // 64 B (PW = 10) / 96 B (PW = 16)
   uint32_t pk[PW + (PW % 4 == 2 ? 0 : 2)];  // the read's 2-bit codes, 16 bases per word
 };
 
-template <int PW>
-__device__ __forceinline__ void gf_load_read_words_lds(const uint32_t* s_pk, const uint32_t* s_iv, uint32_t pos, int L,
-                                                       uint32_t (&pk)[PW], uint32_t (&iv)[PW]) {
-  constexpr int IW = (PW + 1) / 2;
-  const uint32_t w0 = pos >> 4;
-  const uint32_t sh = 2u * (pos & 15u);
-  uint32_t raw[PW + 1];
-#pragma unroll
-  for (int j = 0; j < PW + 1; ++j) raw[j] = s_pk[w0 + j];
-#pragma unroll
-  for (int j = 0; j < PW; ++j) pk[j] = __builtin_amdgcn_alignbit(raw[j + 1], raw[j], sh);
-  const uint32_t v0 = pos >> 5;
-  const uint32_t vs = pos & 31u;
-  uint32_t rv[IW + 1];
-#pragma unroll
-  for (int j = 0; j < IW + 1; ++j) rv[j] = s_iv[v0 + j];
-#pragma unroll
-  for (int j = 0; j < IW; ++j) {
-    uint32_t b = __builtin_amdgcn_alignbit(rv[j + 1], rv[j], vs);
-    const int k = L - 32 * j;  // bases at or beyond the end of the read are unusable
-    if (k < 32) b |= k <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << k);
-    iv[2 * j] = gf_spread16(b);
-    if (2 * j + 1 < PW) iv[2 * j + 1] = gf_spread16(b >> 16);
-  }
-}
-
-#ifndef GF_SV_WAVES_PER_SIMD
-#define GF_SV_WAVES_PER_SIMD 4
-#endif
-template <int PW>
-__global__ __launch_bounds__(256, PW <= 10 ? GF_SV_WAVES_PER_SIMD : 3) void gf_k_seedverify_fused(
-    GfTable T, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets, int64_t n, int lmax,
-    int mark_too_long, uint8_t* __restrict__ counts, GfPipeEntryW<PW>* __restrict__ list_b,
-    unsigned int* __restrict__ blk_cnt, int64_t per_block, unsigned int* __restrict__ ctr) {
-  // Each wavefront stages and processes its own groups of 64 reads: no block barrier in the
-  // loop, so a wave waiting on its random probes never holds the other three back.
-  constexpr int TILE_BYTES = 64 * 16 * PW;         // ASCII bytes staged per tile (64 reads of 16*PW bases)
-  constexpr int TILE_CHUNKS = TILE_BYTES / 16 + 1;  // +1: the span starts at a 16-byte boundary at or below its first read
-  constexpr int PK_WORDS = TILE_CHUNKS + PW + 2;
-  constexpr int IV_WORDS = (TILE_CHUNKS + PW + 2) / 2 + 2;
-  __shared__ uint32_t s_pk_all[4][PK_WORDS];
-  __shared__ uint32_t s_iv_all[4][IV_WORDS];
-  __shared__ unsigned int s_cnt;
-  if (threadIdx.x == 0) s_cnt = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint32_t* s_pk = s_pk_all[wave];
-  uint32_t* s_iv = s_iv_all[wave];
-  const int64_t r_lo = (int64_t)blockIdx.x * per_block;
-  const int64_t r_hi = r_lo + per_block < n ? r_lo + per_block : n;
-  GfPipeEntryW<PW>* my_list = list_b + r_lo;
-  for (int64_t g0 = r_lo + 64 * (int64_t)wave; g0 < r_hi; g0 += 256) {
-   const int64_t g1 = g0 + 64 < r_hi ? g0 + 64 : r_hi;
-   int64_t r0 = g0;
-   while (r0 < g1) {
-    // the reads r0 .. r0+nfit-1 (a prefix of the group) fit in the tile
-    const uintptr_t a0 = (uintptr_t)(bases + offsets[r0]) & ~(uintptr_t)15;
-    const int64_t r = r0 + lane;
-    int64_t off0 = 0, off1 = 0;
-    if (r < g1) {
-      off0 = offsets[r];
-      off1 = offsets[r + 1];
-    }
-    const bool fits = r < g1 && (uintptr_t)(bases + off1) - a0 <= (uintptr_t)TILE_BYTES;
-    int nfit = __popcll(__ballot(fits));
-    const bool oversize = nfit == 0;  // a single read larger than the tile: far beyond lmax, nothing to stage
-    if (oversize) nfit = 1;
-    gf_wave_lds_sync();  // the previous tile's LDS reads are done
-    if (!oversize) {
-      const uintptr_t span_end = (uintptr_t)(bases + offsets[r0 + nfit]);
-      const uint32_t chunks = (uint32_t)((span_end - a0 + 15) >> 4);
-      for (uint32_t c = lane; c < chunks; c += 64) {
-        const uint4 q = *(const uint4*)(a0 + 16 * (uintptr_t)c);
-        uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
-        gf_convert4_bits(q.x, c0, b0);
-        gf_convert4_bits(q.y, c1, b1);
-        gf_convert4_bits(q.z, c2, b2);
-        gf_convert4_bits(q.w, c3, b3);
-        s_pk[c] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-        ((uint16_t*)s_iv)[c] = (uint16_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12));
-      }
-    }
-    gf_wave_lds_sync();
-    const bool in_range = lane < nfit;
-    bool undecided = false;
-    uint32_t e_v1v2 = 0, e_todo[4] = {0, 0, 0, 0};
-    uint32_t pk[PW], iv[PW];
-#pragma unroll
-    for (int j = 0; j < PW; ++j) pk[j] = 0;
-    if (in_range) {
-      const int64_t len64 = off1 - off0;
-      if (len64 > lmax) {
-        if (mark_too_long) counts[r] = GF_COUNT_TOO_LONG;  // else: a longer class owns this read
-      } else if (len64 < GF_KMER + 2 * (GF_MAJOR_KEYS / 2 - 1)) {
-        counts[r] = 0;  // fewer than 20 stride-2 windows: count1 < 20 whatever they hit
-      } else {
-        const int L = (int)len64;
-        gf_load_read_words_lds<PW>(s_pk, s_iv, (uint32_t)((uintptr_t)(bases + off0) - a0), L, pk, iv);
-#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 1
-        { uint32_t a = 0; for (int j = 0; j < PW; ++j) a ^= pk[j] ^ iv[j]; counts[r] = (uint8_t)(a == 0x1234567u); }
-#else
-        // clean stride-2 windows of the read (all 16 bases usable): bit 4t of word j = window 8j+t
-        uint32_t cw[PW];
-        gf_clean_windows<PW>(iv, cw);
-        int nvalid = 0;
-#pragma unroll
-        for (int j = 0; j < PW; ++j) nvalid += __popc(cw[j] & 0x11111111u);
-        // seeds at bases 0, 32, 64, 96 (word aligned: the key is one word).  All four go
-        // through the presence filter together (L2 hits).
-        uint32_t K = GF_NONE_LIN;  // candidate diagonal: site code of read base 0
-        {
-          uint32_t key[4];
-          bool ok[4];
-          uint32_t fw[4], fb[4];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int wj = 2 * s < PW ? 2 * s : 0;
-            key[s] = pk[wj];
-            ok[s] = (2 * s < PW) && (cw[wj] & 1u);
-            if (T.bloom_in_l2) {
-              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[s] >> 4));  // the window's last 14 bases
-              fb[s] = GF_BLOOM_BITS(h2);
-              fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // unconditional: always in range
-            }
-          }
-          if (T.bloom_in_l2) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) ok[s] = ok[s] && (fw[s] & fb[s]) == fb[s];
-          }
-#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 3
-          if (nvalid + ok[0] + 2 * ok[1] + 4 * ok[2] + 8 * ok[3] == 0x1234567) counts[r] = 1;
-          ok[0] = ok[1] = ok[2] = ok[3] = false;
-#endif
-          // Round 1: every read probes the first of its seeds that passed the filter — an
-          // on-target read is done here with one L2-missing request.  Round 2: the reads still
-          // without a diagonal probe all their remaining seeds together.  (A wave runs every
-          // round any of its lanes needs: two rounds, not one per seed.)
-          uint32_t okm = (ok[0] ? 1u : 0u) | (ok[1] ? 2u : 0u) | (ok[2] ? 4u : 0u) | (ok[3] ? 8u : 0u);
-          if (okm) {
-            const int s1 = __builtin_ctz(okm);
-            okm &= okm - 1;
-            const uint32_t k1 = s1 == 0 ? key[0] : (s1 == 1 ? key[1] : (s1 == 2 ? key[2] : key[3]));
-            const uint32_t val = gf_lookup(T, k1);
-            if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s1;
-          }
-#ifndef GF_SV_R2
-#define GF_SV_R2 3  // seeds probed together in round 2
-#endif
-          if (K == GF_NONE_LIN && okm) {
-            uint4 q[GF_SV_R2][4];
-            bool act[GF_SV_R2];
-#pragma unroll
-            for (int s = 1; s <= GF_SV_R2; ++s) {
-              act[s - 1] = (okm >> s) & 1u;
-              if (act[s - 1]) {
-                const uint4* p = (const uint4*)(T.slots + (size_t)gf_bucket_of(key[s], T.nbuckets) * GF_SLOTS_PER_BUCKET);
-                q[s - 1][0] = p[0]; q[s - 1][1] = p[1]; q[s - 1][2] = p[2]; q[s - 1][3] = p[3];
-              }
-            }
-#pragma unroll
-            for (int s = 1; s <= GF_SV_R2; ++s) {
-              if (act[s - 1] && K == GF_NONE_LIN) {
-                bool ovf;
-                uint32_t val = gf_match_bucket(q[s - 1][0], q[s - 1][1], q[s - 1][2], q[s - 1][3], key[s], ovf);
-                if (ovf) val = gf_lookup(T, key[s]);  // the key may sit in a later bucket (2 % of buckets)
-                if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
-              }
-            }
-#pragma unroll
-            for (int s = GF_SV_R2 + 1; s < 4; ++s) {
-              if (((okm >> s) & 1u) && K == GF_NONE_LIN) {
-                const uint32_t val = gf_lookup(T, key[s]);
-                if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
-              }
-            }
-          }
-        }
-#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 4
-        if (K == 0x1234567u) counts[r] = 1;
-        K = GF_NONE_LIN;
-#endif
-        // verify the candidate diagonal
-        int v1 = 0, v2 = 0, nver = 0;
-        uint32_t vm[PW];  // verified windows, same sparse layout as cw
-#pragma unroll
-        for (int j = 0; j < PW; ++j) vm[j] = 0;
-        if (K != GF_NONE_LIN) {
-          const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
-          const uint32_t bo = 2u * (K & 15u);
-          uint32_t gdr[PW + 1], ubr[PW + 1];
-#pragma unroll
-          for (int j = 0; j < PW + 1; ++j) {
-            const uint2 v = gp[j];
-            gdr[j] = v.x;
-            ubr[j] = v.y;
-          }
-          uint32_t zz[PW], cl[PW];
-#pragma unroll
-          for (int j = 0; j < PW; ++j) {
-            const uint32_t g = __builtin_amdgcn_alignbit(gdr[j + 1], gdr[j], bo);
-            const uint32_t x = pk[j] ^ g;
-            zz[j] = ((x | (x >> 1)) & 0x55555555u) | iv[j];  // mismatching or unusable base
-          }
-          gf_clean_windows<PW>(zz, cl);
-#pragma unroll
-          for (int j = 0; j < PW; ++j) {
-            const uint32_t u = __builtin_amdgcn_alignbit(ubr[j + 1], ubr[j], bo);
-            vm[j] = cl[j] & u & 0x11111111u;
-            v1 += __popc(vm[j]);
-          }
-          nver = v1;
-        }
-        // every other diagonal gets at most one vote per window that can still vote
-        const int open = nvalid - nver;
-        if (v1 + open < GF_MAJOR_KEYS / 2 || v2 + open < GF_MINOR_KEYS / 2) {
-          counts[r] = 0;
-        } else {
-          undecided = true;
-          e_v1v2 = (uint32_t)v1 | ((uint32_t)v2 << 8);
-#pragma unroll
-          for (int j = 0; j < PW; ++j)
-            e_todo[j >> 2] |= gf_gather_nibble_lsb(cw[j] & ~vm[j]) << (8 * (j & 3));
-        }
-#endif  // GF_ABLATE_SV == 1
-      }
-    }
-    const unsigned int slot_b = gf_wave_append_lds(undecided, &s_cnt);
-    if (undecided) {
-      // 16-byte stores: the entry is a multiple of 16 bytes and 16-byte aligned
-      uint4* dst = (uint4*)(my_list + slot_b);
-      dst[0] = make_uint4((uint32_t)r, e_v1v2, e_todo[0], e_todo[1]);
-      dst[1] = make_uint4(e_todo[2], e_todo[3], pk[0], pk[1]);
-#pragma unroll
-      for (int j = 2; j + 3 < PW; j += 4) dst[(j + 6) / 4] = make_uint4(pk[j], pk[j + 1], pk[j + 2], pk[j + 3]);
-      if (PW % 4 == 0) dst[(PW + 4) / 4] = make_uint4(pk[PW - 2], pk[PW - 1], 0u, 0u);
-    }
-    r0 += nfit;
-   }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt;
-}
-
-// ---- streaming form of the fused kernel (default) ----
-// Same decisions as gf_k_seedverify_fused, but a read's words are never held in registers
-// all at once: they stay in the wave's LDS tile and are cut out word by word wherever they
-// are needed (clean-window bits, seeds, verification, list entry).  The per-lane state is a
-// few rolling words, so twice as many waves fit on a SIMD — and the kernel is bound by how
-// many random probes the CU keeps in flight, not by arithmetic.
+// ---- K_seedverify, fused with packing (default) ----
+// Each wavefront stages its own groups of 64 reads (no block barrier in the loop).  A read's
+// words are never held in registers all at once: they stay in the wave's LDS tile and are
+// cut out word by word wherever they are needed (clean-window bits, seeds, verification,
+// list entry), so the per-lane state is a few rolling words.
 __device__ __forceinline__ uint32_t gf_cut_pk(const uint32_t* s_pk, uint32_t w0, uint32_t sh, int j) {
   return __builtin_amdgcn_alignbit(s_pk[w0 + j + 1], s_pk[w0 + j], sh);
 }
@@ -1080,51 +835,75 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt;
 }
 
-// ---- K_probe over the fused kernel's entries: the read's codes come with the entry ----
+// ---- K_filter / K_buckets: the undecided reads, in two dense passes ----
+// K_filter (thread per undecided read) asks the presence filter about every unverified
+// window, two windows per look-up (they share a 14-mer; L2 hits only): a window the filter
+// rules out cannot vote, so with P windows left  v1 + P < 20 or v2 + P < 10  ->  [].  The
+// reads that remain (the filter's false positives and the reads that really hit the
+// table) are compacted in place to the front of the block's list region, their `todo`
+// replaced by the windows still standing.
+// K_buckets (thread per remaining read) probes those windows' buckets, as many at a time
+// as must miss before the read can die, h = windows that voted; stops as soon as
+// v1 + h + left < 20 or v2 + h + left < 10 -> [].  Survivors go to the exact kernel.
+// (One kernel doing both kept every wave in the bucket loop for as long as its unluckiest
+// lane: most of its instructions were executed for a handful of lanes.)
 template <int PW>
-__global__ __launch_bounds__(256) void gf_k_probe_fused(GfTable T, const GfPipeEntryW<PW>* __restrict__ list_b,
-                                                        const unsigned int* __restrict__ blk_cnt, int64_t per_block,
-                                                        uint8_t* __restrict__ counts, uint32_t* __restrict__ list_c,
-                                                        unsigned int* __restrict__ ctr) {
-  // the read's codes live in LDS for the duration of its probes ([word][thread]: each
-  // thread reads only its own column, conflict-free)
-  __shared__ uint32_t s_pk[(PW + 1) * 256];
+__device__ __forceinline__ void gf_entry_load(const GfPipeEntryW<PW>* e, uint32_t& r, uint32_t& v1v2, uint32_t (&m)[4],
+                                              uint32_t (&pk)[PW + 1]) {
+  constexpr int EW = sizeof(GfPipeEntryW<PW>) / 16;
+  uint4 ew[EW];
+  const uint4* src = (const uint4*)e;
+#pragma unroll
+  for (int j = 0; j < EW; ++j) ew[j] = src[j];
+  r = ew[0].x;
+  v1v2 = ew[0].y;
+  m[0] = ew[0].z; m[1] = ew[0].w; m[2] = ew[1].x; m[3] = ew[1].y;
+  pk[0] = ew[1].z;
+  pk[1] = ew[1].w;
+#pragma unroll
+  for (int j = 2; j < PW; ++j) {
+    const uint4 q = ew[(j + 6) / 4];
+    const int k = (j + 6) % 4;
+    pk[j] = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
+  }
+  pk[PW] = 0;
+}
+
+template <int PW>
+__device__ __forceinline__ void gf_entry_store(GfPipeEntryW<PW>* e, uint32_t r, uint32_t v1v2, const uint32_t (&m)[4],
+                                               const uint32_t (&pk)[PW + 1]) {
+  uint4* dst = (uint4*)e;
+  dst[0] = make_uint4(r, v1v2, m[0], m[1]);
+  dst[1] = make_uint4(m[2], m[3], pk[0], pk[1]);
+#pragma unroll
+  for (int j = 2; j + 3 < PW; j += 4) dst[(j + 6) / 4] = make_uint4(pk[j], pk[j + 1], pk[j + 2], pk[j + 3]);
+  if (PW % 4 == 0) dst[(PW + 4) / 4] = make_uint4(pk[PW - 2], pk[PW - 1], 0u, 0u);
+}
+
+template <int PW>
+__global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW<PW>* __restrict__ list_b,
+                                                         const unsigned int* __restrict__ blk_cnt, int64_t per_block,
+                                                         uint8_t* __restrict__ counts,
+                                                         unsigned int* __restrict__ blk_cnt2) {
+  __shared__ unsigned int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
   const unsigned int nb = blk_cnt[blockIdx.x];
-  const GfPipeEntryW<PW>* my_list = list_b + (int64_t)blockIdx.x * per_block;
-  const unsigned int nb_round = (nb + 63u) & ~63u;  // whole waves stay in the loop for the ballot
-  for (unsigned int t = threadIdx.x; t < nb_round; t += blockDim.x) {
-    bool to_full = false;
-    uint32_t r = 0;
+  GfPipeEntryW<PW>* my_list = list_b + (int64_t)blockIdx.x * per_block;
+  for (unsigned int t0 = 0; t0 < nb; t0 += 256) {
+    const unsigned int t = t0 + threadIdx.x;
+    bool alive = false;
+    uint32_t r = 0, v1v2 = 0, m[4] = {0, 0, 0, 0}, pk[PW + 1];
+    uint32_t pp[4] = {0, 0, 0, 0};  // windows the filter could not rule out
     if (t < nb) {
-      constexpr int EW = sizeof(GfPipeEntryW<PW>) / 16;
-      uint4 ew[EW];
-      const uint4* src = (const uint4*)(my_list + t);
-#pragma unroll
-      for (int j = 0; j < EW; ++j) ew[j] = src[j];
-      r = ew[0].x;
-      const int v1 = (int)(ew[0].y & 0xFFu), v2 = (int)((ew[0].y >> 8) & 0xFFu);
-      uint32_t m0 = ew[0].z, m1 = ew[0].w, m2 = ew[1].x, m3 = ew[1].y;
-      int left = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
-      int h = 0;
-      uint32_t pk[PW + 1];
-      pk[0] = ew[1].z;
-      pk[1] = ew[1].w;
-#pragma unroll
-      for (int j = 2; j < PW; ++j) {
-        const uint4 q = ew[(j + 6) / 4];
-        const int k = (j + 6) % 4;
-        pk[j] = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
-      }
-      pk[PW] = 0;
-#pragma unroll
-      for (int j = 0; j <= PW; ++j) s_pk[j * 256 + threadIdx.x] = pk[j];  // phase 2 indexes the words dynamically
-      // phase 1: presence filter over every unverified window, two windows per look-up
-      uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // windows the filter could not rule out
+      gf_entry_load<PW>(my_list + t, r, v1v2, m, pk);
+      const int v1 = (int)(v1v2 & 0xFFu), v2 = (int)((v1v2 >> 8) & 0xFFu);
+      int npos = 0, rem = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);  // not ruled out / not asked yet
       bool dead = false;
       if (T.bloom_words) {
-        const uint32_t td[4] = {m0, m1, m2, m3};
-        uint32_t pp[4] = {0, 0, 0, 0};
-        int npos = 0, rem = left;  // not ruled out so far / not asked yet
+        // windows 2q and 2q+1 share the 14-mer at bases 4q+2 .. 4q+15: one lookup for both.
+        // Fully unrolled over the pairs (compile-time shifts on the words in registers),
+        // four look-ups in flight per step.
 #pragma unroll
         for (int q0 = 0; q0 < 4 * PW; q0 += 4) {
           if (!dead) {
@@ -1133,11 +912,11 @@ __global__ __launch_bounds__(256) void gf_k_probe_fused(GfTable T, const GfPipeE
             for (int u = 0; u < 4; ++u) {
               const int q = q0 + u;
               const int wbit = (2 * q) & 31, wword = (2 * q) >> 5;
-              both[u] = wword < 4 ? (td[wword] >> wbit) & 3u : 0u;
+              both[u] = wword < 4 ? (m[wword] >> wbit) & 3u : 0u;
               const int b0 = 4 * q + 2;  // first base of the shared 14-mer
               const int j = b0 >> 4;
               const uint32_t sh14 = 2u * (uint32_t)(b0 & 15);
-              const uint32_t s14 = ((pk[j] >> sh14) | (pk[j + 1] << (32u - sh14))) & 0x0FFFFFFFu;  // sh14 is never 0
+              const uint32_t s14 = __builtin_amdgcn_alignbit(pk[j + 1], pk[j], sh14) & 0x0FFFFFFFu;
               const uint32_t h2 = GF_BLOOM_H2(gf_mix32(s14));
               bits[u] = GF_BLOOM_BITS(h2);
               word[u] = 0;
@@ -1157,14 +936,47 @@ __global__ __launch_bounds__(256) void gf_k_probe_fused(GfTable T, const GfPipeE
             dead = (v1 + npos + rem < GF_MAJOR_KEYS / 2) || (v2 + npos + rem < GF_MINOR_KEYS / 2);
           }
         }
-        p0 = pp[0]; p1 = pp[1]; p2 = pp[2]; p3 = pp[3];
       } else {
-        p0 = m0; p1 = m1; p2 = m2; p3 = m3;
+        pp[0] = m[0]; pp[1] = m[1]; pp[2] = m[2]; pp[3] = m[3];
+        const int left = rem;
+        dead = (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
       }
-      left = __popc(p0) + __popc(p1) + __popc(p2) + __popc(p3);
-      // phase 2: the exact bucket probe of the remaining windows, stopping as soon as
-      // v1 + h + left < 20 or v2 + h + left < 10
-      dead = dead || (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
+      if (dead) counts[r] = 0;
+      alive = !dead;
+    }
+    __syncthreads();  // this chunk's entries are in registers: the compacted ones may overwrite them
+    const unsigned int slot = gf_wave_append_lds(alive, &s_cnt);
+    if (alive) gf_entry_store<PW>(my_list + slot, r, v1v2, pp, pk);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt2[blockIdx.x] = s_cnt;
+}
+
+template <int PW>
+__global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPipeEntryW<PW>* __restrict__ list_b,
+                                                          const unsigned int* __restrict__ blk_cnt2,
+                                                          int64_t per_block, uint8_t* __restrict__ counts,
+                                                          uint32_t* __restrict__ list_c,
+                                                          unsigned int* __restrict__ ctr) {
+  // the read's codes live in LDS for the duration of its probes ([word][thread]: each
+  // thread reads only its own column, conflict-free)
+  __shared__ uint32_t s_pk[(PW + 1) * 256];
+  const unsigned int nb = blk_cnt2[blockIdx.x];
+  const GfPipeEntryW<PW>* my_list = list_b + (int64_t)blockIdx.x * per_block;
+  const unsigned int nb_round = (nb + 63u) & ~63u;  // whole waves stay in the loop for the ballot
+  for (unsigned int t = threadIdx.x; t < nb_round; t += blockDim.x) {
+    bool to_full = false;
+    uint32_t r = 0;
+    if (t < nb) {
+      uint32_t v1v2, p[4], pk[PW + 1];
+      gf_entry_load<PW>(my_list + t, r, v1v2, p, pk);
+      const int v1 = (int)(v1v2 & 0xFFu), v2 = (int)((v1v2 >> 8) & 0xFFu);
+#pragma unroll
+      for (int j = 0; j <= PW; ++j) s_pk[j * 256 + threadIdx.x] = pk[j];  // the loop indexes the words dynamically
+      uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+      int left = __popc(p0) + __popc(p1) + __popc(p2) + __popc(p3);
+      int h = 0;
+      bool dead = (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
       while (!dead && left > 0) {
         // the read dies only after at least `need` more probes miss: issue that many (up to
         // 4) bucket probes together instead of one round trip each

@@ -107,7 +107,7 @@ struct gf_index {
   std::map<hipStream_t, Workspace> ws;
   std::mutex ws_mu;
   hipEvent_t ev0{}, ev1{};
-  hipEvent_t ev_stage[5]{};  // pipeline stage boundaries: pack | seedverify | probe | full
+  hipEvent_t ev_stage[5]{};  // pipeline stage boundaries: seed+verify | filter | buckets | exact kernel
   bool stages_recorded = false;
   std::mutex prof_mu;
 
@@ -168,7 +168,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
 
   std::unique_ptr<gf_index> ix(new gf_index());
   ix->device = dev;
-  if (const char* e = getenv("GF_MAP_VARIANT")) ix->map_variant = atoi(e) >= 0 && atoi(e) <= 4 ? atoi(e) : 0;  // experiments
+  if (const char* e = getenv("GF_MAP_VARIANT")) ix->map_variant = atoi(e) >= 0 && atoi(e) <= 3 ? atoi(e) : 0;  // experiments
   hipDeviceProp_t prop;
   GF_HIP(hipGetDeviceProperties(&prop, dev));
   ix->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -403,10 +403,8 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
   // each launch skips the reads of the other classes, so short reads always get the
   // small-LDS kernel with the seed+verify first pass.
   const int top = max_read_len <= 256 ? 0 : (max_read_len <= 1024 ? 1 : 2);
-  if (idx->map_variant == 0 || idx->map_variant == 4) {
-    // flat pipeline, K_pack fused into K_seedverify through LDS (4 = the register-resident
-    // form of the fused kernel, kept for A/B timing)
-    const bool streamk = idx->map_variant == 0;
+  if (idx->map_variant == 0) {
+    // flat pipeline, K_pack fused into K_seedverify through LDS
     const bool small = max_read_len <= 160;
     const int lmax = top == 0 ? max_read_len : 256;
     const int mark = top == 0 ? 1 : 0;
@@ -420,7 +418,7 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     const size_t sz_lc = al((size_t)n * sizeof(uint32_t));
     const size_t sz_bc = al((size_t)nblk * sizeof(unsigned int));
     const size_t sz_ctr = 256;
-    const size_t need = sz_lb + sz_lc + sz_bc + sz_ctr;
+    const size_t need = sz_lb + sz_lc + 2 * sz_bc + sz_ctr;
     std::lock_guard<std::mutex> ws_lock(mix->ws_mu);  // held until this call's launches are queued
     void* ws_base = nullptr;
     {
@@ -431,35 +429,31 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     void* list_b = (void*)wp; wp += sz_lb;
     uint32_t* list_c = (uint32_t*)wp; wp += sz_lc;
     unsigned int* blk_cnt = (unsigned int*)wp; wp += sz_bc;
+    unsigned int* blk_cnt2 = (unsigned int*)wp; wp += sz_bc;
     unsigned int* ctr = (unsigned int*)wp;
     GF_HIP(hipMemsetAsync(ctr, 0, 64, st));
     const int g_full = idx->n_cus * 8;
-    if (prof) {
-      GF_HIP(hipEventRecord(mix->ev_stage[0], st));
-      GF_HIP(hipEventRecord(mix->ev_stage[1], st));  // no separate pack stage
-    }
+    if (prof) GF_HIP(hipEventRecord(mix->ev_stage[0], st));
     if (small) {
       constexpr int PW = 10;  // 16-base words of a read of up to 160 bases
-      if (streamk)
-        hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
-                           lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
-      else
-        hipLaunchKernelGGL((gf_k_seedverify_fused<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
-                           lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
+      hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
+                         lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
+      if (prof) GF_HIP(hipEventRecord(mix->ev_stage[1], st));
+      hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
+                         (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, counts, blk_cnt2);
       if (prof) GF_HIP(hipEventRecord(mix->ev_stage[2], st));
-      hipLaunchKernelGGL((gf_k_probe_fused<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
-                         (const GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, counts, list_c, ctr);
+      hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
+                         (const GfPipeEntryW<PW>*)list_b, blk_cnt2, per_block, counts, list_c, ctr);
     } else {
       constexpr int PW = 16;  // up to 256 bases
-      if (streamk)
-        hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
-                           lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
-      else
-        hipLaunchKernelGGL((gf_k_seedverify_fused<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
-                           lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
+      hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
+                         lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
+      if (prof) GF_HIP(hipEventRecord(mix->ev_stage[1], st));
+      hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
+                         (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, counts, blk_cnt2);
       if (prof) GF_HIP(hipEventRecord(mix->ev_stage[2], st));
-      hipLaunchKernelGGL((gf_k_probe_fused<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
-                         (const GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, counts, list_c, ctr);
+      hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
+                         (const GfPipeEntryW<PW>*)list_b, blk_cnt2, per_block, counts, list_c, ctr);
     }
     if (prof) GF_HIP(hipEventRecord(mix->ev_stage[3], st));
     hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(g_full), dim3(256), 0, st, idx->table, bases, offsets,
@@ -970,7 +964,7 @@ int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, in
 }
 
 int gf_set_map_variant(gf_index* idx, int32_t variant) {
-  if (!idx || variant < 0 || variant > 4) return fail(GF_ERR_ARG, "bad variant");
+  if (!idx || variant < 0 || variant > 3) return fail(GF_ERR_ARG, "bad variant");
   idx->map_variant = variant;
   return GF_OK;
 }

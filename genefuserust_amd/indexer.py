@@ -241,7 +241,8 @@ class Indexer:
         _lib.check(_lib.lib().gf_set_map_variant(self._handle(), int(variant)))
 
     def last_stage_ms(self):
-        """Flat pipeline: ms of (gf_k_pack, gf_k_seedverify, gf_k_probe, gf_k_map_reads_list)."""
+        """Flat pipeline: ms of its four kernels (seed+verify, filter, buckets, exact kernel; variant 3:
+        pack, seed+verify, probe, exact kernel)."""
         import ctypes as C
         out = (C.c_float * 4)()
         _lib.check(_lib.lib().gf_last_stage_ms(self._handle(), out))
