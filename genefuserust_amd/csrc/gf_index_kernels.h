@@ -228,7 +228,7 @@ __global__ void gf_k_build_bloom(const uint64_t* slots, uint64_t nslots, uint32_
     const uint64_t v = slots[s];
     if (((uint32_t)v & GF_VAL_LOW) == 0) continue;
     const uint32_t key = (uint32_t)(v >> 32);
-    const uint32_t ha = GF_BLOOM_H2(gf_mix32(key >> 4)), hb = GF_BLOOM_H2(gf_mix32(key & 0x0FFFFFFFu));
+    const uint32_t ha = GF_BLOOM_HASH((key >> 4)), hb = GF_BLOOM_HASH((key & 0x0FFFFFFFu));
     atomicOr(bloom + GF_BLOOM_WORD(ha, nwords), GF_BLOOM_BITS(ha));
     atomicOr(bloom + GF_BLOOM_WORD(hb, nwords), GF_BLOOM_BITS(hb));
   }

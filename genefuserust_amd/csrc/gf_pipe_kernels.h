@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void gf_k_seedverify(GfTable T, GfStream S, co
             key[s] = pk[wj];
             ok[s] = (2 * s < PW) && (cw[wj] & 1u);
             if (T.bloom_in_l2) {
-              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[s] >> 4));  // the window's last 14 bases
+              const uint32_t h2 = GF_BLOOM_HASH((key[s] >> 4));  // the window's last 14 bases
               fb[s] = GF_BLOOM_BITS(h2);
               fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // unconditional: always in range
             }
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
               const int j = b0 >> 4;
               const uint32_t sh14 = 2u * (uint32_t)(b0 & 15);
               const uint32_t s14 = ((pk[j] >> sh14) | (pk[j + 1] << (32u - sh14))) & 0x0FFFFFFFu;  // sh14 is never 0
-              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(s14));
+              const uint32_t h2 = GF_BLOOM_HASH((s14));
               bits[u] = GF_BLOOM_BITS(h2);
               word[u] = 0;
               if (both[u]) word[u] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             uint32_t fw[4], fb[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(key[s] >> 4));  // the window's last 14 bases
+              const uint32_t h2 = GF_BLOOM_HASH((key[s] >> 4));  // the window's last 14 bases
               fb[s] = GF_BLOOM_BITS(h2);
               fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // unconditional: always in range
             }
@@ -753,12 +753,12 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // one bucket probe at a time, in seed order, until one names a diagonal: an
           // on-target read costs one L2-missing request here
           uint32_t K = GF_NONE_LIN;  // candidate diagonal: site code of read base 0
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            if (((okm >> s) & 1u) && K == GF_NONE_LIN) {
-              const uint32_t val = gf_lookup(T, key[s]);
-              if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
-            }
+          while (okm != 0 && K == GF_NONE_LIN) {  // (a wave runs as many rounds as its unluckiest lane needs)
+            const int s = __builtin_ctz(okm);
+            okm &= okm - 1;
+            const uint32_t ks = s == 0 ? key[0] : (s == 1 ? key[1] : (s == 2 ? key[2] : key[3]));
+            const uint32_t val = gf_lookup(T, ks);
+            if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
           }
 #if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 4
           if (K == 0x1234567u) counts[r] = 1;
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
               const int j = b0 >> 4;
               const uint32_t sh14 = 2u * (uint32_t)(b0 & 15);
               const uint32_t s14 = __builtin_amdgcn_alignbit(pk[j + 1], pk[j], sh14) & 0x0FFFFFFFu;
-              const uint32_t h2 = GF_BLOOM_H2(gf_mix32(s14));
+              const uint32_t h2 = GF_BLOOM_HASH((s14));
               bits[u] = GF_BLOOM_BITS(h2);
               word[u] = 0;
               if (both[u]) word[u] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];

@@ -84,10 +84,18 @@ struct GfTable {
   int32_t n_genes;
 };
 
-// filter word and bit pair of a 14-mer x (28 bits), from its mixed hash h = gf_mix32(x)
-#define GF_BLOOM_H2(h) ((h) * 0x9E3779B1u)
-#define GF_BLOOM_WORD(h2, nwords) ((uint32_t)(((uint64_t)(h2) * (uint64_t)(nwords)) >> 32))
-#define GF_BLOOM_BITS(h2) ((1u << ((h2) & 31u)) | (1u << (((h2) >> 5) & 31u)))
+// filter word and bit pair of a 14-mer x (28 bits).  One multiplicative hash: the word comes
+// from its high bits (mulhi), the two bit positions from its low bits folded with the
+// middle ones.  (A full murmur finaliser here cost four 32-bit multiplies per look-up,
+// quarter-rate instructions, in a kernel that does 34 look-ups per read.)
+#ifdef GF_BLOOM_OLDHASH
+#define GF_BLOOM_HASH(x) (gf_mix32(x) * 0x9E3779B1u)
+#define GF_BLOOM_BITS(h) ((1u << ((h) & 31u)) | (1u << (((h) >> 5) & 31u)))
+#else
+#define GF_BLOOM_HASH(x) ((uint32_t)(x) * 0x9E3779B1u)
+#define GF_BLOOM_BITS(h) ((1u << (((h) ^ ((h) >> 15)) & 31u)) | (1u << ((((h) ^ ((h) >> 15)) >> 5) & 31u)))
+#endif
+#define GF_BLOOM_WORD(h, nwords) ((uint32_t)(((uint64_t)(h) * (uint64_t)(nwords)) >> 32))
 
 #if defined(__HIPCC__)
 #define GF_HD __host__ __device__ __forceinline__

@@ -22,16 +22,17 @@ for f in find("trace/**/*kernel_stats.csv"):
             r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 for f in find("trace/**/*kernel_trace.csv"):
     rows = list(csv.DictReader(open(f)))
-    for hot in ("gf_k_map_reads", "gf_k_pack", "gf_k_seedverify", "gf_k_probe"):
-      ks = [r for r in rows if hot in r.get("Kernel_Name", "")]
+    names = sorted({r.get("Kernel_Name", "").split("(")[0].replace("void ", "") for r in rows
+                    if "gf_k_" in r.get("Kernel_Name", "")})
+    for hot in names:
+      ks = [r for r in rows if r.get("Kernel_Name", "").split("(")[0].replace("void ", "") == hot]
       if ks:
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ks]
         r0 = ks[0]
         print("\n## %s dispatches: n=%d avg=%.3f ms min=%.3f max=%.3f  VGPR=%s SGPR=%s LDS=%s grid=%s wg=%s" % (
-            r0["Kernel_Name"].split("(")[0].replace("void ", ""),
-            len(d), sum(d) / len(d) / 1e6, min(d) / 1e6, max(d) / 1e6, r0.get("VGPR_Count"), r0.get("SGPR_Count"),
+            hot, len(d), sum(d) / len(d) / 1e6, min(d) / 1e6, max(d) / 1e6, r0.get("VGPR_Count"), r0.get("SGPR_Count"),
             r0.get("LDS_Block_Size"), r0.get("Grid_Size"), r0.get("Workgroup_Size")))
-HOT = ("gf_k_map_reads", "gf_k_pack", "gf_k_seedverify", "gf_k_probe")
+HOT = ("gf_k_",)
 for f in find("pmc_*/**/*counter_collection.csv"):
     rows = list(csv.DictReader(open(f)))
     acc = defaultdict(lambda: defaultdict(list))
