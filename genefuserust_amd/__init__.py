@@ -8,5 +8,6 @@ mirror of the reference interface.  See DESIGN.md.
 from .indexer import Fusion, Gene, GenePos, Indexer, SeqMatch, resolve_gene_slice, unpack_matches  # noqa: F401
 from .fusion_mapper import FusionMapper, ReadMatch, edit_distance, reverse_complement  # noqa: F401
 from .read_pair import MergedRead, SequenceReadPair, fast_merge_batch, fast_merge_device, scan_pair_end  # noqa: F401
+from .fastq import FastqBatch, FastqReader, FastqReaderPair, fastq_cut_device, record_lines  # noqa: F401
 
 __version__ = "0.1.0"

@@ -120,6 +120,12 @@ def lib() -> C.CDLL:
     L.gf_fusion_map_read.restype = C.c_int
     L.gf_index_fusion_map_read.argtypes = [vp, vp, C.c_char_p, i64, C.POINTER(GfSeqMatch), i32, C.POINTER(GfReadMatch)]
     L.gf_index_fusion_map_read.restype = C.c_int
+    L.gf_fastq_workspace_bytes.argtypes = [i64]
+    L.gf_fastq_workspace_bytes.restype = i64
+    L.gf_fastq_index_device.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp]
+    L.gf_fastq_index_device.restype = C.c_int
+    L.gf_fastq_gather_device.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp, vp, i64, vp, vp, vp]
+    L.gf_fastq_gather_device.restype = C.c_int
     L.gf_fast_merge_find_device.argtypes = [vp] * 7 + [i64, i32] + [vp] * 3
     L.gf_fast_merge_find_device.restype = C.c_int
     L.gf_fast_merge_write_device.argtypes = [vp] * 7 + [i64] + [vp] * 5

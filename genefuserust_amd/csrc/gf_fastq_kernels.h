@@ -1,0 +1,174 @@
+// SURVEY.md §8(f)-2 — FASTQ ingest on the device: FastqReader::read
+// (src/core/fastq_reader.rs:75-147) for a whole text buffer resident in HBM.
+//
+// The reference reads four lines per record with BufRead::read_line (name, sequence,
+// strand, quality), strips one trailing '\n' from each (a '\r' stays part of the line),
+// accepts a last line without '\n', and stops at the first record that has fewer than four
+// lines.  On the device that is: find every '\n' (ordered positions: count per tile, scan
+// the tile totals, write), then record i owns lines 4i .. 4i+3, and its sequence and quality
+// lines are copied into the back-to-back `bases` / `quals` + `offsets` layout that
+// gf_map_reads_device and gf_fast_merge_*_device take.  (gzip stays on the host.)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gf_compact_kernels.h"
+
+#define GF_FQ_TILE 16384                        // text bytes per block
+#define GF_FQ_PER (GF_FQ_TILE / GF_CTHREADS)    // 64 contiguous bytes per thread
+
+// bit 7 of each byte of the result = that byte of x is '\n'
+__device__ __forceinline__ uint32_t gf_newline_flags(uint32_t x) {
+  const uint32_t v = x ^ 0x0A0A0A0Au;
+  return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
+}
+
+// the thread's 64 bytes as 16 dwords; bytes at or beyond n read as 0
+__device__ __forceinline__ void gf_fq_load64(const uint8_t* __restrict__ text, int64_t n, int64_t p0, uint32_t (&w)[16]) {
+  if (p0 + GF_FQ_PER <= n && (((uintptr_t)(text + p0)) & 15u) == 0) {
+    const uint4* q = (const uint4*)(text + p0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint4 v = q[k];
+      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int64_t p = p0 + 4 * k + b;
+        if (p < n) x |= (uint32_t)text[p] << (8 * b);
+      }
+      w[k] = x;
+    }
+  }
+}
+
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_count(const uint8_t* __restrict__ text, int64_t n,
+                                                             uint32_t* __restrict__ tile_counts) {
+  __shared__ int s_wave[4];
+  const int64_t p0 = (int64_t)blockIdx.x * GF_FQ_TILE + (int64_t)threadIdx.x * GF_FQ_PER;
+  int c = 0;
+  if (p0 < n) {
+    uint32_t w[16];
+    gf_fq_load64(text, n, p0, w);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c += __popc(gf_newline_flags(w[k]));
+  }
+  int total;
+  gf_block_exclusive_scan(c, s_wave, &total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = (uint32_t)total;
+}
+
+// nl_pos[k] = byte offset of the k-th '\n' (k < cap); *n_lines = lines in the text, counting
+// a last line without '\n'
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_write(const uint8_t* __restrict__ text, int64_t n,
+                                                             const int64_t* __restrict__ tile_offsets,
+                                                             const int64_t* __restrict__ n_newlines,
+                                                             int64_t* __restrict__ nl_pos, int64_t cap,
+                                                             int64_t* __restrict__ n_lines) {
+  __shared__ int s_wave[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_lines = *n_newlines + ((n > 0 && text[n - 1] != '\n') ? 1 : 0);
+  const int64_t p0 = (int64_t)blockIdx.x * GF_FQ_TILE + (int64_t)threadIdx.x * GF_FQ_PER;
+  uint32_t w[16];
+  int c = 0;
+  if (p0 < n) {
+    gf_fq_load64(text, n, p0, w);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      w[k] = gf_newline_flags(w[k]);
+      c += __popc(w[k]);
+    }
+  }
+  int total;
+  int64_t pos = tile_offsets[blockIdx.x] + gf_block_exclusive_scan(c, s_wave, &total);
+  if (!c) return;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    uint32_t f = w[k];
+    while (f) {
+      const int b = __builtin_ctz(f) >> 3;  // byte index inside the dword
+      f &= f - 1;
+      if (pos < cap) nl_pos[pos] = p0 + 4 * k + b;
+      ++pos;
+    }
+  }
+}
+
+// [start, end) of line k (k < n_lines)
+__device__ __forceinline__ void gf_fq_line(const int64_t* __restrict__ nl_pos, int64_t n_newlines, int64_t n_bytes,
+                                           int64_t k, int64_t& start, int64_t& end) {
+  start = k ? nl_pos[k - 1] + 1 : 0;
+  end = k < n_newlines ? nl_pos[k] : n_bytes;
+}
+
+#define GF_FQ_RTILE 256  // records per block of the two record kernels: one per thread
+
+// sequence length of every record, summed per tile of 256 records
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_lens(const int64_t* __restrict__ nl_pos, int64_t n_newlines,
+                                                            int64_t n_bytes, int64_t n_rec,
+                                                            uint32_t* __restrict__ tile_counts) {
+  __shared__ int s_wave[4];
+  const int64_t r = (int64_t)blockIdx.x * GF_FQ_RTILE + threadIdx.x;
+  int c = 0;
+  if (r < n_rec) {
+    int64_t s, e;
+    gf_fq_line(nl_pos, n_newlines, n_bytes, 4 * r + 1, s, e);
+    c = (int)(e - s);
+  }
+  int total;
+  gf_block_exclusive_scan(c, s_wave, &total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = (uint32_t)total;
+}
+
+// offsets[] of the records, then the sequence and quality lines copied a wavefront per
+// record, 64 bytes per step.  A quality line shorter than its sequence is padded with '!'
+// (Phred 0), a longer one is cut: both are counted in *n_bad (the reference does not check,
+// and its fast_merge would panic on the short ones).
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __restrict__ text,
+                                                              const int64_t* __restrict__ nl_pos, int64_t n_newlines,
+                                                              int64_t n_bytes, int64_t n_rec,
+                                                              const int64_t* __restrict__ tile_offsets,
+                                                              int64_t* __restrict__ offsets,
+                                                              uint8_t* __restrict__ bases, uint8_t* __restrict__ quals,
+                                                              int64_t cap_bytes, unsigned long long* __restrict__ n_bad) {
+  __shared__ int s_wave[4];
+  __shared__ int64_t s_ss[GF_FQ_RTILE], s_qs[GF_FQ_RTILE], s_dst[GF_FQ_RTILE];
+  __shared__ int s_len[GF_FQ_RTILE], s_qlen[GF_FQ_RTILE];
+  const int64_t t0 = (int64_t)blockIdx.x * GF_FQ_RTILE;
+  const int64_t r = t0 + threadIdx.x;
+  int len = 0, qlen = 0;
+  int64_t ss = 0, qs = 0;
+  if (r < n_rec) {
+    int64_t se, qe;
+    gf_fq_line(nl_pos, n_newlines, n_bytes, 4 * r + 1, ss, se);
+    gf_fq_line(nl_pos, n_newlines, n_bytes, 4 * r + 3, qs, qe);
+    len = (int)(se - ss);
+    qlen = (int)(qe - qs);
+  }
+  int total;
+  const int64_t pos = tile_offsets[blockIdx.x] + gf_block_exclusive_scan(len, s_wave, &total);
+  if (r < n_rec) {
+    offsets[r] = pos;
+    if (r == n_rec - 1) offsets[n_rec] = pos + len;
+    if (qlen != len) atomicAdd(n_bad, 1ull);
+  }
+  s_ss[threadIdx.x] = ss; s_qs[threadIdx.x] = qs; s_dst[threadIdx.x] = pos;
+  s_len[threadIdx.x] = len; s_qlen[threadIdx.x] = qlen;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int in_tile = (int)((n_rec - t0) < GF_FQ_RTILE ? (n_rec - t0) : GF_FQ_RTILE);
+  for (int i = wave; i < in_tile; i += GF_CTHREADS / 64) {
+    const int64_t src = s_ss[i], qsrc = s_qs[i], dst = s_dst[i];
+    const int ln = s_len[i], ql = s_qlen[i];
+    for (int k = lane; k < ln; k += 64) {
+      if (dst + k < cap_bytes) {
+        bases[dst + k] = text[src + k];
+        quals[dst + k] = k < ql ? text[qsrc + k] : (uint8_t)'!';
+      }
+    }
+  }
+}

@@ -20,6 +20,7 @@
 #include "gf_index_kernels.h"
 #include "gf_map_kernels.h"
 #include "gf_merge_kernels.h"
+#include "gf_fastq_kernels.h"
 #include "gf_pipe_kernels.h"
 #include "gf_table.h"
 
@@ -961,6 +962,77 @@ int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, in
   GF_HIP(hipMemcpy(out_seq, dob.p, (size_t)*out_len, hipMemcpyDeviceToHost));
   GF_HIP(hipMemcpy(out_qual, doq.p, (size_t)*out_len, hipMemcpyDeviceToHost));
   return 1;
+}
+
+// ---- FastqReader::read on the device ----
+// tiles of either kind a text of n_bytes can need: 16 KB text tiles, or tiles of 256 records (a
+// record is at least its four newlines)
+static inline int64_t fq_tiles(int64_t n_bytes) { return n_bytes / (4 * GF_FQ_RTILE) + 2; }
+
+int64_t gf_fastq_workspace_bytes(int64_t n_bytes) {
+  if (n_bytes < 0) return 0;
+  return 64 + fq_tiles(n_bytes) * (int64_t)(sizeof(uint32_t) + sizeof(int64_t)) + 16;
+}
+
+int gf_fastq_index_device(const gf_index* idx, const void* d_text, int64_t n_bytes, void* d_nl_pos, int64_t cap_lines,
+                          void* d_n_lines, void* d_workspace, void* stream) {
+  if (!idx || n_bytes < 0 || cap_lines < 0) return fail(GF_ERR_ARG, "null index or negative size");
+  if (!d_n_lines || !d_workspace || (n_bytes > 0 && !d_text) || (cap_lines > 0 && !d_nl_pos))
+    return fail(GF_ERR_ARG, "null device pointer");
+  DeviceGuard guard(idx->device);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ntiles = (n_bytes + GF_FQ_TILE - 1) / GF_FQ_TILE;
+  uintptr_t w = ((uintptr_t)d_workspace + 15) & ~(uintptr_t)15;
+  int64_t* tile_offsets = (int64_t*)w;
+  uint32_t* tile_counts = (uint32_t*)(w + (size_t)fq_tiles(n_bytes) * sizeof(int64_t));
+  int64_t* n_lines = (int64_t*)d_n_lines;  // [0] lines, [1] newlines
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(gf_k_fq_count, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text, n_bytes,
+                       tile_counts);
+    GF_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, tile_counts, ntiles, tile_offsets, n_lines + 1);
+  GF_HIP(hipGetLastError());
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(gf_k_fq_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text, n_bytes,
+                       tile_offsets, n_lines + 1, (int64_t*)d_nl_pos, cap_lines, n_lines);
+    GF_HIP(hipGetLastError());
+  } else {
+    GF_HIP(hipMemsetAsync(n_lines, 0, sizeof(int64_t), st));
+  }
+  return GF_OK;
+}
+
+int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_bytes, const void* d_nl_pos,
+                           int64_t n_newlines, int64_t n_records, void* d_offsets, void* d_bases, void* d_quals,
+                           int64_t cap_bytes, void* d_n_bad, void* d_workspace, void* stream) {
+  if (!idx || n_bytes < 0 || n_newlines < 0 || n_records < 0 || cap_bytes < 0)
+    return fail(GF_ERR_ARG, "null index or negative size");
+  if (!d_offsets || !d_n_bad || !d_workspace) return fail(GF_ERR_ARG, "null device pointer");
+  // record i owns lines 4i .. 4i+3: all of them must exist
+  if (4 * n_records > n_newlines + 1) return fail(GF_ERR_ARG, "n_records exceeds the lines of the text");
+  DeviceGuard guard(idx->device);
+  hipStream_t st = (hipStream_t)stream;
+  GF_HIP(hipMemsetAsync(d_n_bad, 0, sizeof(unsigned long long), st));
+  if (n_records == 0) {
+    GF_HIP(hipMemsetAsync(d_offsets, 0, sizeof(int64_t), st));
+    return GF_OK;
+  }
+  if (!d_text || !d_nl_pos || (cap_bytes > 0 && (!d_bases || !d_quals))) return fail(GF_ERR_ARG, "null device pointer");
+  const int64_t ntiles = (n_records + GF_FQ_RTILE - 1) / GF_FQ_RTILE;
+  if (ntiles >= fq_tiles(n_bytes)) return fail(GF_ERR_ARG, "n_records impossible for a text of n_bytes");
+  uintptr_t w = ((uintptr_t)d_workspace + 15) & ~(uintptr_t)15;
+  int64_t* tile_offsets = (int64_t*)w;
+  uint32_t* tile_counts = (uint32_t*)(w + (size_t)fq_tiles(n_bytes) * sizeof(int64_t));
+  int64_t* total = tile_offsets + fq_tiles(n_bytes) - 1;  // last slot is spare
+  hipLaunchKernelGGL(gf_k_fq_lens, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const int64_t*)d_nl_pos, n_newlines,
+                     n_bytes, n_records, tile_counts);
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, tile_counts, ntiles, tile_offsets, total);
+  hipLaunchKernelGGL(gf_k_fq_gather, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text,
+                     (const int64_t*)d_nl_pos, n_newlines, n_bytes, n_records, tile_offsets, (int64_t*)d_offsets,
+                     (uint8_t*)d_bases, (uint8_t*)d_quals, cap_bytes, (unsigned long long*)d_n_bad);
+  GF_HIP(hipGetLastError());
+  return GF_OK;
 }
 
 int gf_set_map_variant(gf_index* idx, int32_t variant) {

@@ -227,6 +227,28 @@ int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, in
                   const char* r_qual, int32_t len2, char* out_seq, char* out_qual, int32_t* out_len,
                   int32_t* out_diff);
 
+/* FastqReader::read (fastq_reader.rs:75-147) for a whole FASTQ text resident in HBM (plain text:
+ * gzip stays on the host).  A line is the bytes up to, not including, a '\n' — a '\r' stays
+ * in the line, as in the reference; the last line may lack its '\n'; record i owns lines
+ * 4i (name), 4i+1 (sequence), 4i+2 (strand), 4i+3 (quality); a trailing group of fewer than
+ * four lines is no record.
+ *
+ * gf_fastq_index_device: d_nl_pos[k] (int64, k < cap_lines) = byte offset of the k-th '\n';
+ *   d_n_lines (int64[2]) = {lines in the text, newlines in the text}.  Records = lines / 4.
+ * gf_fastq_gather_device: copies the sequence and quality lines of records 0..n_records-1
+ *   back to back into d_bases / d_quals (capacity cap_bytes each; n_bytes always suffices)
+ *   with d_offsets (int64[n_records+1]) — the layout gf_map_reads_device and
+ *   gf_fast_merge_*_device take.  A quality line is cut or padded with '!' to its sequence's
+ *   length; *d_n_bad (uint64) counts the records where that happened.  Name and strand lines
+ *   are located by d_nl_pos for whoever needs them.
+ * d_workspace: gf_fastq_workspace_bytes(n_bytes) bytes, the same buffer for both calls. */
+int64_t gf_fastq_workspace_bytes(int64_t n_bytes);
+int gf_fastq_index_device(const gf_index* idx, const void* d_text, int64_t n_bytes, void* d_nl_pos, int64_t cap_lines,
+                          void* d_n_lines, void* d_workspace, void* stream);
+int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_bytes, const void* d_nl_pos,
+                           int64_t n_newlines, int64_t n_records, void* d_offsets, void* d_bases, void* d_quals,
+                           int64_t cap_bytes, void* d_n_bad, void* d_workspace, void* stream);
+
 /* --- instrumentation -------------------------------------------------------
  * With profiling on, gf_map_reads_device brackets its mapping kernel with HIP
  * events on the launch stream; gf_last_map_kernel_ms synchronises on them and

@@ -260,3 +260,14 @@ def fast_merge(l_seq: str, l_qual: str, r_seq: str, r_qual: str):
                     qual[off + i] = chr(min(ord(a) + ord(b) - 33, ord("Z")))
             return "".join(seq), "".join(qual), len(mism)
     return None
+
+
+# ---- FastqReader::read (fastq_reader.rs:75-147), from its description: four
+# lines per record, one trailing newline stripped from each, a last line without newline
+# counts, the first incomplete record ends the file.
+
+def fastq_records(text: bytes):
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()  # nothing after the final newline: not a line
+    return [tuple(lines[4 * i:4 * i + 4]) for i in range(len(lines) // 4)]

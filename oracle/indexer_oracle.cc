@@ -702,4 +702,35 @@ int32_t orc_fast_merge(const char* l_seq, const char* l_qual, int32_t len1, cons
   return 1;
 }
 
+// ---- FastqReader::read (src/core/fastq_reader.rs:75-147) over an
+// in-memory text, one read_line at a time like the reference.  out[8*i ..] = (start, length)
+// of the name, sequence, strand and quality lines of record i; returns the number of
+// records (writes at most cap of them).
+static bool orc_read_line(const char* text, int64_t n, int64_t& cur, int64_t& start, int64_t& len) {
+  if (cur >= n) return false;  // read_line returned 0 bytes (:80, :94, :108, :123)
+  start = cur;
+  int64_t p = cur;
+  while (p < n && text[p] != '\n') ++p;
+  len = p - cur;                     // the trailing newline is popped if it is there (:82-87)
+  cur = p < n ? p + 1 : p;
+  return true;
+}
+
+int64_t orc_fastq_cut(const char* text, int64_t n, int64_t* out, int64_t cap) {
+  int64_t cur = 0, n_rec = 0;
+  for (;;) {
+    int64_t st[4], ln[4];
+    bool ok = true;
+    for (int k = 0; k < 4 && ok; ++k) ok = orc_read_line(text, n, cur, st[k], ln[k]);
+    if (!ok) break;  // read() returns None: the scanners stop
+    if (n_rec < cap)
+      for (int k = 0; k < 4; ++k) {
+        out[8 * n_rec + 2 * k] = st[k];
+        out[8 * n_rec + 2 * k + 1] = ln[k];
+      }
+    ++n_rec;
+  }
+  return n_rec;
+}
+
 }  // extern "C"

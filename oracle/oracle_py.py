@@ -67,6 +67,8 @@ def lib() -> C.CDLL:
     L.orc_fast_merge.argtypes = [C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p,
                                  C.POINTER(i32), C.POINTER(i32)]
     L.orc_fast_merge.restype = i32
+    L.orc_fastq_cut.argtypes = [C.c_char_p, i64, vp, i64]
+    L.orc_fastq_cut.restype = i64
     _lib = L
     return L
 
@@ -206,3 +208,11 @@ def fast_merge(l_seq: bytes, l_qual: bytes, r_seq: bytes, r_qual: bytes):
     if not ok:
         return None
     return oseq.raw[:olen.value], oqual.raw[:olen.value], int(odiff.value)
+
+
+def fastq_cut(text: bytes):
+    """FastqReader::read until it returns None: list of (name, sequence, strand, quality)."""
+    n = lib().orc_fastq_cut(text, len(text), None, 0)
+    out = np.zeros((max(n, 1), 8), dtype=np.int64)
+    lib().orc_fastq_cut(text, len(text), out.ctypes.data, n)
+    return [tuple(text[out[i, 2 * k]:out[i, 2 * k] + out[i, 2 * k + 1]] for k in range(4)) for i in range(n)]
