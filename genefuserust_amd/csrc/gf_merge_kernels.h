@@ -264,9 +264,10 @@ __global__ __launch_bounds__(256) void gf_k_merge_find_bytes(const uint8_t* __re
   }
 }
 
-// ---- K_merge_write: block per 256 pairs; the merged ones are listed in LDS and each is
-// written by one wavefront, a byte per lane (read.rs:379-428).  in_len[p] = merged length
-// from the find kernel (0 = not merged), out_pos[p] = where it goes. ----
+// ---- K_merge_write: block per 256 pairs; each thread fetches its pair's layout, the merged
+// pairs are listed in LDS and each is written by one wavefront, 64 bytes per step
+// (read.rs:379-428).  in_len[p] = merged length from the find kernel (0 = not merged),
+// out_pos[p] = where it goes. ----
 __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restrict__ l_bases,
                                                         const uint8_t* __restrict__ l_quals,
                                                         const int64_t* __restrict__ l_off,
@@ -278,50 +279,69 @@ __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restric
                                                         uint8_t* __restrict__ out_bases,
                                                         uint8_t* __restrict__ out_quals) {
   __shared__ unsigned int s_cnt;
-  __shared__ uint32_t s_ids[256];
+  __shared__ int64_t s_l[256], s_r[256], s_dst[256];
+  __shared__ int s_len1[256], s_len2[256], s_mlen[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
     __syncthreads();
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     const int64_t p0 = base + threadIdx.x;
-    const bool merged = p0 < n && in_len[p0] > 0;
+    const int ml = p0 < n ? in_len[p0] : 0;
+    const bool merged = ml > 0;
     const unsigned int slot = gf_wave_append_lds(merged, &s_cnt);
-    if (merged) s_ids[slot] = (uint32_t)threadIdx.x;
+    if (merged) {
+      const int64_t lo = l_off[p0], ro = r_off[p0];
+      s_l[slot] = lo;
+      s_r[slot] = ro;
+      s_len1[slot] = (int)(l_off[p0 + 1] - lo);
+      s_len2[slot] = (int)(r_off[p0 + 1] - ro);
+      s_mlen[slot] = ml;
+      s_dst[slot] = out_pos[p0];
+    }
     __syncthreads();
     const unsigned int cnt = s_cnt;
     for (unsigned int e = wave; e < cnt; e += 4) {
-      const int64_t p = base + s_ids[e];
-      const int len1 = (int)(l_off[p + 1] - l_off[p]), len2 = (int)(r_off[p + 1] - r_off[p]);
-      const int mlen = in_len[p];
+      const int len1 = s_len1[e], len2 = s_len2[e], mlen = s_mlen[e];
       const int offset = mlen - len2, olen = len1 - offset;
-      const uint8_t* s1 = l_bases + l_off[p];
-      const uint8_t* q1 = l_quals + l_off[p];
-      const uint8_t* s2 = r_bases + r_off[p];
-      const uint8_t* q2 = r_quals + r_off[p];
-      uint8_t* os = out_bases + out_pos[p];
-      uint8_t* oq = out_quals + out_pos[p];
-      for (int k = lane; k < mlen; k += 64) {
-        uint8_t cs, cq;
-        if (k < offset) {
-          cs = s1[k];
-          cq = q1[k];
-        } else {
-          const int i = k - offset;
-          cs = gf_complement(s2[len2 - 1 - i]);
-          cq = q2[len2 - 1 - i];
-          if (i < olen) {
-            const uint8_t c1 = s1[k], a = q1[k];
-            if (c1 != cs) {
-              if (a >= '?' && cq <= '0') { cs = c1; cq = a; }
-            } else {
-              const uint32_t q = (uint32_t)a + (uint32_t)cq - 33u;  // add the pair's qualities, cap at 'Z'
-              cq = q >= (uint32_t)'Z' ? (uint8_t)'Z' : (uint8_t)q;
-            }
+      const uint8_t* s1 = l_bases + s_l[e];
+      const uint8_t* q1 = l_quals + s_l[e];
+      const uint8_t* s2 = r_bases + s_r[e];
+      const uint8_t* q2 = r_quals + s_r[e];
+      uint8_t* os = out_bases + s_dst[e];
+      uint8_t* oq = out_quals + s_dst[e];
+      for (int k0 = 0; k0 < mlen; k0 += 256) {  // four 64-byte steps in flight
+        uint8_t a1[4], b1[4], a2[4], b2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + 64 * u + lane;
+          a1[u] = b1[u] = a2[u] = b2[u] = 0;
+          if (k < mlen) {
+            if (k < len1) { a1[u] = s1[k]; b1[u] = q1[k]; }
+            if (k >= offset) { a2[u] = s2[len2 - 1 - (k - offset)]; b2[u] = q2[len2 - 1 - (k - offset)]; }
           }
         }
-        os[k] = cs;
-        oq[k] = cq;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + 64 * u + lane;
+          if (k < mlen) {
+            uint8_t cs = a1[u], cq = b1[u];
+            if (k >= offset) {
+              cs = gf_complement(a2[u]);
+              cq = b2[u];
+              if (k - offset < olen) {
+                if (a1[u] != cs) {
+                  if (b1[u] >= '?' && cq <= '0') { cs = a1[u]; cq = b1[u]; }
+                } else {
+                  const uint32_t q = (uint32_t)b1[u] + (uint32_t)cq - 33u;  // add the pair's qualities, cap at 'Z'
+                  cq = q >= (uint32_t)'Z' ? (uint8_t)'Z' : (uint8_t)q;
+                }
+              }
+            }
+            os[k] = cs;
+            oq[k] = cq;
+          }
+        }
       }
     }
   }
