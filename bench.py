@@ -213,12 +213,12 @@ def main() -> None:
                 traffic = None
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": ["gf_map_reads_device = 4 kernels: gf_k_seedverify_stream + gf_k_probe_filter + "
-                       "gf_k_probe_buckets + gf_k_map_reads_list; achieved uses their summed duration",
-                       "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
-                       "gf_k_map_reads_short<4,1> (wave per read, seed+verify)",
-                       "gf_map_reads_device = 4 kernels: gf_k_pack + gf_k_seedverify + gf_k_probe + "
-                       "gf_k_map_reads_list; achieved uses their summed duration"][args.variant],
+            "kernel": {0: "gf_map_reads_device = 4 kernels: gf_k_seedverify_stream + gf_k_probe_filter + "
+                          "gf_k_probe_buckets + gf_k_map_reads_list; achieved uses their summed duration",
+                       1: "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
+                       2: "gf_k_map_reads_short<4,1> (wave per read, seed+verify)",
+                       3: "gf_map_reads_device = 4 kernels: gf_k_pack + gf_k_seedverify + gf_k_probe + "
+                          "gf_k_map_reads_list; achieved uses their summed duration"}[args.variant],
             "stage_ms": stage_ms,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

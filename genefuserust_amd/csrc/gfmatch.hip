@@ -146,6 +146,71 @@ static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** 
   return GF_OK;
 }
 
+// ---- the flat pipeline's four launches for one span of reads ----
+struct FlatWs {
+  void* list_b;
+  uint32_t* list_c;
+  unsigned int* blk_cnt;
+  unsigned int* blk_cnt2;
+  unsigned int* ctr;
+};
+struct FlatPlan {
+  int nblk;
+  int64_t per_block;
+  size_t sz_lb, sz_lc, sz_bc, sz_ctr;
+  size_t bytes() const { return sz_lb + sz_lc + 2 * sz_bc + sz_ctr; }
+};
+static FlatPlan flat_plan(int64_t n, int n_cus, bool small) {
+  FlatPlan p;
+  int blk_mult = 32;
+  if (const char* e = getenv("GF_NBLK_MULT")) blk_mult = std::max(1, atoi(e));  // experiments
+  p.nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)n_cus * blk_mult));
+  p.per_block = (n + p.nblk - 1) / p.nblk;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t esz = small ? sizeof(GfPipeEntryW<10>) : sizeof(GfPipeEntryW<16>);
+  p.sz_lb = al((size_t)n * esz);
+  p.sz_lc = al((size_t)n * sizeof(uint32_t));
+  p.sz_bc = al((size_t)p.nblk * sizeof(unsigned int));
+  p.sz_ctr = 256;
+  return p;
+}
+static FlatWs flat_carve(uint8_t* wp, const FlatPlan& p) {
+  FlatWs w;
+  w.list_b = (void*)wp; wp += p.sz_lb;
+  w.list_c = (uint32_t*)wp; wp += p.sz_lc;
+  w.blk_cnt = (unsigned int*)wp; wp += p.sz_bc;
+  w.blk_cnt2 = (unsigned int*)wp; wp += p.sz_bc;
+  w.ctr = (unsigned int*)wp;
+  return w;
+}
+// ev[0..4] (optional): stage boundaries
+template <int PW>
+static int launch_flat(const gf_index* idx, hipStream_t st, const uint8_t* bases, const int64_t* offsets, int64_t n,
+                       int lmax, int mark, uint8_t* counts, gf_seqmatch* matches, const FlatWs& w, const FlatPlan& p,
+                       hipEvent_t* ev) {
+  GF_HIP(hipMemsetAsync(w.ctr, 0, 64, st));
+  if (ev) GF_HIP(hipEventRecord(ev[0], st));
+  // Seed+verify is bound by L2-missing requests, not by waves in flight: four blocks per CU
+  // (40 KB of LDS each, padded with dynamic LDS) measured 2.5 % faster than the six its
+  // registers allow.
+  size_t pad_lds = 24000;
+  if (const char* e = getenv("GF_SV_PAD_LDS")) pad_lds = (size_t)atoi(e);  // experiments
+  hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(p.nblk), dim3(256), pad_lds, st, idx->table, bases, offsets, n, lmax,
+                     mark, counts, (GfPipeEntryW<PW>*)w.list_b, w.blk_cnt, p.per_block, w.ctr);
+  if (ev) GF_HIP(hipEventRecord(ev[1], st));
+  hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(p.nblk), dim3(256), 0, st, idx->table, (GfPipeEntryW<PW>*)w.list_b,
+                     w.blk_cnt, p.per_block, counts, w.blk_cnt2);
+  if (ev) GF_HIP(hipEventRecord(ev[2], st));
+  hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(p.nblk), dim3(256), 0, st, idx->table,
+                     (const GfPipeEntryW<PW>*)w.list_b, w.blk_cnt2, p.per_block, counts, w.list_c, w.ctr);
+  if (ev) GF_HIP(hipEventRecord(ev[3], st));
+  hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(idx->n_cus * 8), dim3(256), 0, st, idx->table, bases, offsets,
+                     w.list_c, w.ctr + 1, counts, matches);
+  GF_HIP(hipGetLastError());
+  if (ev) GF_HIP(hipEventRecord(ev[4], st));
+  return GF_OK;
+}
+
 extern "C" {
 
 const char* gf_last_error(void) { return g_err.c_str(); }
@@ -409,60 +474,19 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     const bool small = max_read_len <= 160;
     const int lmax = top == 0 ? max_read_len : 256;
     const int mark = top == 0 ? 1 : 0;
-    int blk_mult = 32;
-    if (const char* e = getenv("GF_NBLK_MULT")) blk_mult = std::max(1, atoi(e));  // experiments
-    const int nblk = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * blk_mult);
-    const int64_t per_block = (n + nblk - 1) / nblk;
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t esz = small ? sizeof(GfPipeEntryW<10>) : sizeof(GfPipeEntryW<16>);
-    const size_t sz_lb = al((size_t)n * esz);
-    const size_t sz_lc = al((size_t)n * sizeof(uint32_t));
-    const size_t sz_bc = al((size_t)nblk * sizeof(unsigned int));
-    const size_t sz_ctr = 256;
-    const size_t need = sz_lb + sz_lc + 2 * sz_bc + sz_ctr;
     std::lock_guard<std::mutex> ws_lock(mix->ws_mu);  // held until this call's launches are queued
-    void* ws_base = nullptr;
     {
-      int wrc = acquire_workspace(mix, st, need, &ws_base);
+      const FlatPlan p = flat_plan(n, idx->n_cus, small);
+      void* ws_base = nullptr;
+      int wrc = acquire_workspace(mix, st, p.bytes(), &ws_base);
       if (wrc != GF_OK) return wrc;
-    }
-    uint8_t* wp = (uint8_t*)ws_base;
-    void* list_b = (void*)wp; wp += sz_lb;
-    uint32_t* list_c = (uint32_t*)wp; wp += sz_lc;
-    unsigned int* blk_cnt = (unsigned int*)wp; wp += sz_bc;
-    unsigned int* blk_cnt2 = (unsigned int*)wp; wp += sz_bc;
-    unsigned int* ctr = (unsigned int*)wp;
-    GF_HIP(hipMemsetAsync(ctr, 0, 64, st));
-    const int g_full = idx->n_cus * 8;
-    if (prof) GF_HIP(hipEventRecord(mix->ev_stage[0], st));
-    if (small) {
-      constexpr int PW = 10;  // 16-base words of a read of up to 160 bases
-      hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
-                         lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
-      if (prof) GF_HIP(hipEventRecord(mix->ev_stage[1], st));
-      hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
-                         (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, counts, blk_cnt2);
-      if (prof) GF_HIP(hipEventRecord(mix->ev_stage[2], st));
-      hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
-                         (const GfPipeEntryW<PW>*)list_b, blk_cnt2, per_block, counts, list_c, ctr);
-    } else {
-      constexpr int PW = 16;  // up to 256 bases
-      hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(nblk), dim3(256), 0, st, idx->table, bases, offsets, n,
-                         lmax, mark, counts, (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, ctr);
-      if (prof) GF_HIP(hipEventRecord(mix->ev_stage[1], st));
-      hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
-                         (GfPipeEntryW<PW>*)list_b, blk_cnt, per_block, counts, blk_cnt2);
-      if (prof) GF_HIP(hipEventRecord(mix->ev_stage[2], st));
-      hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(nblk), dim3(256), 0, st, idx->table,
-                         (const GfPipeEntryW<PW>*)list_b, blk_cnt2, per_block, counts, list_c, ctr);
-    }
-    if (prof) GF_HIP(hipEventRecord(mix->ev_stage[3], st));
-    hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(g_full), dim3(256), 0, st, idx->table, bases, offsets,
-                       list_c, ctr + 1, counts, matches);
-    GF_HIP(hipGetLastError());
-    if (prof) {
-      GF_HIP(hipEventRecord(mix->ev_stage[4], st));
-      mix->stages_recorded = true;
+      const FlatWs w = flat_carve((uint8_t*)ws_base, p);
+      wrc = small ? launch_flat<10>(idx, st, bases, offsets, n, lmax, mark, counts, matches, w, p,
+                                    prof ? mix->ev_stage : nullptr)
+                  : launch_flat<16>(idx, st, bases, offsets, n, lmax, mark, counts, matches, w, p,
+                                    prof ? mix->ev_stage : nullptr);
+      if (wrc != GF_OK) return wrc;
+      if (prof) mix->stages_recorded = true;
     }
   } else if (idx->map_variant == 3) {
     // flat pipeline with a separate K_pack (kept for A/B measurements against the fused form)
