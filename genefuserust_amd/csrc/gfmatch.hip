@@ -107,6 +107,10 @@ struct gf_index {
   struct Workspace { void* base = nullptr; size_t bytes = 0; };
   std::map<hipStream_t, Workspace> ws;
   std::mutex ws_mu;
+  // device arena of the host-buffer entry points (gf_map_reads, gf_map_reads_hits), grow-only
+  void* stage_base = nullptr;
+  size_t stage_bytes = 0;
+  std::mutex stage_mu;
   hipEvent_t ev0{}, ev1{};
   hipEvent_t ev_stage[5]{};  // pipeline stage boundaries: seed+verify | filter | buckets | exact kernel
   bool stages_recorded = false;
@@ -122,6 +126,7 @@ struct gf_index {
     if (d_bloom) (void)hipFree(d_bloom);
     for (auto& kv : ws)
       if (kv.second.base) (void)hipFree(kv.second.base);
+    if (stage_base) (void)hipFree(stage_base);
     if (have_events) {
       (void)hipEventDestroy(ev0);
       (void)hipEventDestroy(ev1);
@@ -623,9 +628,23 @@ int gf_compact_hits_device(const gf_index* idx, const void* d_counts, const void
 }
 
 // Host-buffer staging shared by gf_map_reads / gf_map_reads_hits.
-static int stage_and_map(const gf_index* idx, const char* bases, const int64_t* offsets, int64_t n,
-                         DevBuf<uint8_t>& d_counts, DevBuf<gf_seqmatch>& d_matches) {
-  if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
+// Host-buffer entry points: one grow-only device arena per index (bases, offsets, counts,
+// matches, hits, compaction workspace), reused from call to call — for a PCIe-bound path the
+// per-call hipMalloc/hipFree of gigabyte buffers cost as much as the copies.  Calls that go
+// through it are serialised by stage_mu.
+struct HostStage {
+  uint8_t* bases = nullptr;     // device pointer such that bases + offsets[r] is read r (host offsets kept as they are)
+  int64_t* offsets = nullptr;
+  uint8_t* counts = nullptr;
+  gf_seqmatch* matches = nullptr;
+  gf_hit* hits = nullptr;
+  int64_t* total = nullptr;
+  uint8_t* compact_ws = nullptr;
+};
+
+static int stage_and_map(gf_index* mix, const char* bases, const int64_t* offsets, int64_t n, int64_t hits_cap,
+                         HostStage& S) {
+  if (n < 0) return fail(GF_ERR_ARG, "negative n");
   if (n > 0 && (!offsets)) return fail(GF_ERR_ARG, "offsets is null");
   int64_t maxlen = 0;
   for (int64_t r = 0; r < n; ++r) {
@@ -636,23 +655,38 @@ static int stage_and_map(const gf_index* idx, const char* bases, const int64_t* 
   if (maxlen > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "a read exceeds GF_MAX_READ_LEN");
   const int64_t b0 = n > 0 ? offsets[0] : 0, b1 = n > 0 ? offsets[n] : 0;
   if (b1 > b0 && !bases) return fail(GF_ERR_ARG, "bases is null");
-  DevBuf<uint8_t> d_bases;
-  DevBuf<int64_t> d_off;
-  GF_HIP(d_bases.alloc((size_t)(b1 - b0) + 16));
-  GF_HIP(d_off.alloc((size_t)n + 1));
-  GF_HIP(d_counts.alloc((size_t)n));
-  GF_HIP(d_matches.alloc((size_t)n * 2));
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t sz_bases = al((size_t)(b1 - b0) + 64), sz_off = al(((size_t)n + 1) * sizeof(int64_t));
+  const size_t sz_counts = al((size_t)n + 1), sz_matches = al(((size_t)n * 2 + 1) * sizeof(gf_seqmatch));
+  const size_t sz_hits = al(((size_t)hits_cap + 1) * sizeof(gf_hit)), sz_total = 256;
+  const size_t sz_cws = al((size_t)gf_compact_workspace_bytes(n) + 16);
+  const size_t need = sz_bases + sz_off + sz_counts + sz_matches + sz_hits + sz_total + sz_cws;
+  if (mix->stage_bytes < need) {
+    if (mix->stage_base) {
+      GF_HIP(hipDeviceSynchronize());
+      GF_HIP(hipFree(mix->stage_base));
+      mix->stage_base = nullptr;
+      mix->stage_bytes = 0;
+    }
+    GF_HIP(hipMalloc(&mix->stage_base, need));
+    mix->stage_bytes = need;
+  }
+  uint8_t* wp = (uint8_t*)mix->stage_base;
+  uint8_t* d_bases = wp; wp += sz_bases;
+  S.offsets = (int64_t*)wp; wp += sz_off;
+  S.counts = wp; wp += sz_counts;
+  S.matches = (gf_seqmatch*)wp; wp += sz_matches;
+  S.hits = (gf_hit*)wp; wp += sz_hits;
+  S.total = (int64_t*)wp; wp += sz_total;
+  S.compact_ws = wp;
+  // the 16-byte boundary at or below the first read is preserved (the kernels stage whole chunks)
+  const size_t lead = (size_t)((uintptr_t)(bases + b0) & 15u);
+  S.bases = d_bases + lead - b0;  // S.bases + offsets[r] = the device copy of read r
   if (n == 0) return GF_OK;
-  // offsets are rebased so that the device buffer starts at the first read
-  std::vector<int64_t> rel((size_t)n + 1);
-  for (int64_t r = 0; r <= n; ++r) rel[(size_t)r] = offsets[r] - b0;
-  if (b1 > b0) GF_HIP(hipMemcpy(d_bases.p, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice));
-  GF_HIP(hipMemcpy(d_off.p, rel.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-  int rc = gf_map_reads_device(idx, d_bases.p, d_off.p, n, (int32_t)std::max<int64_t>(maxlen, 1), d_counts.p,
-                               d_matches.p, nullptr);
-  if (rc != GF_OK) return rc;
-  GF_HIP(hipDeviceSynchronize());
-  return GF_OK;
+  if (b1 > b0) GF_HIP(hipMemcpyAsync(d_bases + lead, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, nullptr));
+  GF_HIP(hipMemcpyAsync(S.offsets, offsets, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, nullptr));
+  return gf_map_reads_device(mix, S.bases, S.offsets, n, (int32_t)std::max<int64_t>(maxlen, 1), S.counts, S.matches,
+                             nullptr);
 }
 
 int gf_map_reads(const gf_index* idx, const char* bases, const int64_t* offsets, int64_t n,
@@ -660,14 +694,15 @@ int gf_map_reads(const gf_index* idx, const char* bases, const int64_t* offsets,
   if (n > 0 && (!out_counts || !out_matches)) return fail(GF_ERR_ARG, "null output buffer");
   if (!idx) return fail(GF_ERR_ARG, "null index");
   DeviceGuard guard(idx->device);
-  DevBuf<uint8_t> d_counts;
-  DevBuf<gf_seqmatch> d_matches;
-  int rc = stage_and_map(idx, bases, offsets, n, d_counts, d_matches);
+  gf_index* mix = const_cast<gf_index*>(idx);
+  std::lock_guard<std::mutex> lk(mix->stage_mu);
+  HostStage S;
+  int rc = stage_and_map(mix, bases, offsets, n, 0, S);
   if (rc != GF_OK || n == 0) return rc;
   std::vector<uint8_t> c8((size_t)n);
   std::vector<gf_seqmatch> m((size_t)n * 2);
-  GF_HIP(hipMemcpy(c8.data(), d_counts.p, (size_t)n, hipMemcpyDeviceToHost));
-  GF_HIP(hipMemcpy(m.data(), d_matches.p, (size_t)n * 2 * sizeof(gf_seqmatch), hipMemcpyDeviceToHost));
+  GF_HIP(hipMemcpy(c8.data(), S.counts, (size_t)n, hipMemcpyDeviceToHost));
+  GF_HIP(hipMemcpy(m.data(), S.matches, (size_t)n * 2 * sizeof(gf_seqmatch), hipMemcpyDeviceToHost));
   for (int64_t r = 0; r < n; ++r) {
     int c = c8[(size_t)r];
     out_counts[r] = c;
@@ -693,25 +728,18 @@ int gf_map_reads_hits(const gf_index* idx, const char* bases, const int64_t* off
   if (!idx) return fail(GF_ERR_ARG, "null index");
   *out_n = 0;
   DeviceGuard guard(idx->device);
-  DevBuf<uint8_t> d_counts;
-  DevBuf<gf_seqmatch> d_matches;
-  int rc = stage_and_map(idx, bases, offsets, n, d_counts, d_matches);
+  gf_index* mix = const_cast<gf_index*>(idx);
+  std::lock_guard<std::mutex> lk(mix->stage_mu);
+  HostStage S;
+  int rc = stage_and_map(mix, bases, offsets, n, cap, S);
   if (rc != GF_OK || n == 0) return rc;
-  DevBuf<gf_hit> d_hits;
-  DevBuf<int64_t> d_total;
-  DevBuf<uint8_t> d_ws;
-  GF_HIP(d_hits.alloc((size_t)cap));
-  GF_HIP(d_total.alloc(1));
-  GF_HIP(d_ws.alloc((size_t)gf_compact_workspace_bytes(n)));
-  rc = gf_compact_hits_device(idx, d_counts.p, d_matches.p, n, read_id_base, d_hits.p, cap, d_total.p, d_ws.p,
-                              nullptr);
+  rc = gf_compact_hits_device(idx, S.counts, S.matches, n, read_id_base, S.hits, cap, S.total, S.compact_ws, nullptr);
   if (rc != GF_OK) return rc;
-  GF_HIP(hipDeviceSynchronize());
   int64_t total = 0;
-  GF_HIP(hipMemcpy(&total, d_total.p, sizeof total, hipMemcpyDeviceToHost));
+  GF_HIP(hipMemcpy(&total, S.total, sizeof total, hipMemcpyDeviceToHost));  // also waits for the launches
   *out_n = total;
   int64_t ncopy = std::min(total, cap);
-  if (ncopy > 0) GF_HIP(hipMemcpy(out_hits, d_hits.p, (size_t)ncopy * sizeof(gf_hit), hipMemcpyDeviceToHost));
+  if (ncopy > 0) GF_HIP(hipMemcpy(out_hits, S.hits, (size_t)ncopy * sizeof(gf_hit), hipMemcpyDeviceToHost));
   return GF_OK;
 }
 

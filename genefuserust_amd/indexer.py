@@ -187,13 +187,17 @@ class Indexer:
         b = np.ascontiguousarray(bases, dtype=np.uint8)
         o = np.ascontiguousarray(offsets, dtype=np.int64)
         n = o.size - 1
-        cap = n if cap is None else cap
-        hits = np.zeros(max(cap, 1), dtype=HIT_DTYPE)
-        total = C.c_int64(0)
-        _lib.check(_lib.lib().gf_map_reads_hits(self._handle(), b.ctypes.data if b.size else None,
-                                                o.ctypes.data, n, read_id_base, hits.ctypes.data, cap,
-                                                C.byref(total)))
-        return hits[:min(int(total.value), cap)]
+        explicit = cap is not None
+        cap = cap if explicit else min(n, max(4096, n // 64))  # hits are a fraction of a percent of the reads
+        while True:
+            hits = np.empty(max(cap, 1), dtype=HIT_DTYPE)
+            total = C.c_int64(0)
+            _lib.check(_lib.lib().gf_map_reads_hits(self._handle(), b.ctypes.data if b.size else None,
+                                                    o.ctypes.data, n, read_id_base, hits.ctypes.data, cap,
+                                                    C.byref(total)))
+            if explicit or int(total.value) <= cap:
+                return hits[:min(int(total.value), cap)]
+            cap = int(total.value)  # a batch of mostly hits: once more with room for all of them
 
     # -- device-resident batch (torch tensors are only carriers of HBM pointers) --
     def map_reads_device(self, bases, offsets, max_read_len: int, counts=None, matches=None, stream=None):
