@@ -529,13 +529,53 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
 // important, ~17 dword gathers per read from it: those were L2 hits, but every one of them
 // is a request against the ~270 G/s L2 ceiling that the presence filter also lives on.
 // An undecided read's packed words travel to K_probe inside its list entry.
+// One undecided read: w[0] = read index in the batch, w[1] = v1 | v2 << 8, w[2 .. 2+NT) = one
+// bit per stride-2 window still to be asked (bit b of word k = window 32k + b), then the
+// read's PW words of 2-bit codes; padded to whole 16-byte vectors.
 template <int PW>
-struct GfPipeEntryW {  // 64 B (PW = 10) / 96 B (PW = 16)
-  uint32_t read;       // read index in the batch
-  uint32_t v1v2;       // v1 | v2 << 8
-  uint32_t todo[4];    // bit w = stride-2 window w is clean and not verified: probe it
-  uint32_t pk[PW + (PW % 4 == 2 ? 0 : 2)];  // the read's 2-bit codes, 16 bases per word
+struct GfPipeEntryW {  // 64 B (PW = 10), 96 B (PW = 16), 112 B (PW = 20)
+  static constexpr int NT = PW <= 16 ? 4 : (PW + 3) / 4;  // 8 windows per word of the read
+  static constexpr int EW = (2 + NT + PW + 3) / 4;        // 16-byte vectors
+  uint32_t w[4 * EW];
 };
+
+template <int PW>
+__device__ __forceinline__ void gf_entry_load(const GfPipeEntryW<PW>* e, uint32_t& r, uint32_t& v1v2,
+                                              uint32_t (&m)[GfPipeEntryW<PW>::NT], uint32_t (&pk)[PW + 1]) {
+  constexpr int NT = GfPipeEntryW<PW>::NT, EW = GfPipeEntryW<PW>::EW;
+  uint32_t w[4 * EW];
+  const uint4* src = (const uint4*)e;
+#pragma unroll
+  for (int j = 0; j < EW; ++j) {
+    const uint4 q = src[j];
+    w[4 * j] = q.x; w[4 * j + 1] = q.y; w[4 * j + 2] = q.z; w[4 * j + 3] = q.w;
+  }
+  r = w[0];
+  v1v2 = w[1];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) m[k] = w[2 + k];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) pk[j] = w[2 + NT + j];
+  pk[PW] = 0;
+}
+
+template <int PW>
+__device__ __forceinline__ void gf_entry_store(GfPipeEntryW<PW>* e, uint32_t r, uint32_t v1v2,
+                                               const uint32_t (&m)[GfPipeEntryW<PW>::NT], const uint32_t (&pk)[PW + 1]) {
+  constexpr int NT = GfPipeEntryW<PW>::NT, EW = GfPipeEntryW<PW>::EW;
+  uint32_t w[4 * EW];
+  w[0] = r;
+  w[1] = v1v2;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) w[2 + k] = m[k];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) w[2 + NT + j] = pk[j];
+#pragma unroll
+  for (int j = 2 + NT + PW; j < 4 * EW; ++j) w[j] = 0;
+  uint4* dst = (uint4*)e;  // the entry is a multiple of 16 bytes and 16-byte aligned
+#pragma unroll
+  for (int j = 0; j < EW; ++j) dst[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+}
 
 // ---- K_seedverify, fused with packing (default) ----
 // Each wavefront stages its own groups of 64 reads (no block barrier in the loop).  A read's
@@ -603,14 +643,19 @@ __device__ __forceinline__ uint32_t gf_window_mask(int nwin, int k) {
 template <int PW>
 __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_k_seedverify_stream(
     GfTable T, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets, int64_t n, int lmax,
-    int mark_too_long, uint8_t* __restrict__ counts, GfPipeEntryW<PW>* __restrict__ list_b,
-    unsigned int* __restrict__ blk_cnt, int64_t per_block, unsigned int* __restrict__ ctr) {
+    int batch_max, uint8_t* __restrict__ counts, GfPipeEntryW<PW>* __restrict__ list_b,
+    unsigned int* __restrict__ blk_cnt, int64_t per_block, uint32_t* __restrict__ list_long,
+    unsigned int* __restrict__ ctr) {
+  // lmax = longest read this kernel maps; reads of lmax+1 .. batch_max bases are handed to the
+  // wave-per-read kernels of the longer classes through list_long (<= 1024 bases from the
+  // front, counter ctr[2]; longer from the back, counter ctr[3]); beyond batch_max: marked.
   constexpr int TILE_BYTES = 64 * 16 * PW;         // ASCII bytes staged per tile (64 reads of 16*PW bases)
   constexpr int TILE_CHUNKS = TILE_BYTES / 16 + 1;  // +1: the span starts at a 16-byte boundary at or below its first read
   constexpr int PK_WORDS = TILE_CHUNKS + PW + 2;
   constexpr int IV_WORDS = (TILE_CHUNKS + PW + 2) / 2 + 2;
   constexpr int NLOAD = (TILE_CHUNKS + 63) / 64;    // 16-byte chunks per lane per tile
   constexpr int IW = (PW + 1) / 2;                  // 32-base words of flag bits per read
+  constexpr int NT = GfPipeEntryW<PW>::NT;          // words of one bit per stride-2 window
   __shared__ uint32_t s_pk_all[4][PK_WORDS];
   __shared__ uint32_t s_iv_all[4][IV_WORDS];
   __shared__ unsigned int s_cnt;
@@ -672,13 +717,18 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       gf_wave_lds_sync();
       __builtin_amdgcn_sched_barrier(0);
       const bool in_range = lane < nfit;
-      bool undecided = false;
-      uint32_t e_v1v2 = 0, e_todo[4] = {0, 0, 0, 0};
+      bool undecided = false, long1k = false, long4k = false;
+      uint32_t e_v1v2 = 0, e_todo[NT];
+#pragma unroll
+      for (int k = 0; k < NT; ++k) e_todo[k] = 0;
       uint32_t w0 = 0, sh = 0;
       if (in_range) {
         const int64_t len64 = off1 - off0;
-        if (len64 > lmax) {
-          if (mark_too_long) counts[r] = GF_COUNT_TOO_LONG;  // else: a longer class owns this read
+        if (len64 > batch_max) {
+          counts[r] = GF_COUNT_TOO_LONG;
+        } else if (len64 > lmax) {
+          long1k = len64 <= 1024;
+          long4k = !long1k;
         } else if (len64 < GF_KMER + 2 * (GF_MAJOR_KEYS / 2 - 1)) {
           counts[r] = 0;  // fewer than 20 stride-2 windows: count1 < 20 whatever they hit
         } else {
@@ -703,7 +753,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           }
           // pass A: the clean stride-2 windows (all 16 bases usable), one bit per window, and
           // the seeds at bases 0, 32, 64, 96
-          uint32_t cwb[4];
+          uint32_t cwb[NT];
           int nvalid;
           uint32_t key[4];
           uint32_t okm = 0;
@@ -712,11 +762,12 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           if (!anybad) {
             nvalid = (L - GF_KMER) / 2 + 1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cwb[k] = gf_window_mask(nvalid, k);
+            for (int k = 0; k < NT; ++k) cwb[k] = gf_window_mask(nvalid, k);
 #pragma unroll
             for (int s = 0; s < 4; ++s) okm |= (2 * s < PW && 16 * s < nvalid ? 1u : 0u) << s;
           } else {
-            cwb[0] = cwb[1] = cwb[2] = cwb[3] = 0;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) cwb[k] = 0;
             nvalid = 0;
             uint32_t z_cur = gf_cut_iv(s_iv, pos, L, 0);
 #pragma unroll
@@ -730,7 +781,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             }
           }
 #if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 1
-          if ((nvalid ^ key[0] ^ key[1] ^ key[2] ^ key[3] ^ cwb[0] ^ cwb[1] ^ cwb[2] ^ cwb[3] ^ okm) == 0x1234567u) counts[r] = 1;
+          if ((nvalid ^ key[0] ^ key[1] ^ key[2] ^ key[3] ^ cwb[0] ^ cwb[1] ^ cwb[2] ^ cwb[NT - 1] ^ okm) == 0x1234567u) counts[r] = 1;
           okm = 0;
 #endif
           // all four seeds go through the presence filter together (L2 hits)
@@ -767,7 +818,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // pass B: verify the candidate diagonal against the genes in site-code space, a
           // word of the read at a time: window w counts iff its 16 bases equal the bases of
           // site K + 2w and that site is the only site of its key
-          uint32_t vmb[4] = {0, 0, 0, 0};  // verified windows, one bit per window like cwb
+          uint32_t vmb[NT];  // verified windows, one bit per window like cwb
+#pragma unroll
+          for (int k = 0; k < NT; ++k) vmb[k] = 0;
           if (K != GF_NONE_LIN) {
             const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
             const uint32_t bo = 2u * (K & 15u);
@@ -798,7 +851,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           }
           int v1 = 0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < NT; ++k) {
             vmb[k] &= cwb[k];  // windows that run past the end of the read compared garbage
             v1 += __popc(vmb[k]);
           }
@@ -810,23 +863,24 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             undecided = true;
             e_v1v2 = (uint32_t)v1;  // v2 = 0: one candidate diagonal per read
 #pragma unroll
-            for (int k = 0; k < 4; ++k) e_todo[k] = cwb[k] & ~vmb[k];
+            for (int k = 0; k < NT; ++k) e_todo[k] = cwb[k] & ~vmb[k];
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       const unsigned int slot_b = gf_wave_append_lds(undecided, &s_cnt);
       if (undecided) {
-        // 16-byte stores: the entry is a multiple of 16 bytes and 16-byte aligned
-        uint4* dst = (uint4*)(my_list + slot_b);
-        dst[0] = make_uint4((uint32_t)r, e_v1v2, e_todo[0], e_todo[1]);
-        dst[1] = make_uint4(e_todo[2], e_todo[3], gf_cut_pk(s_pk, w0, sh, 0), gf_cut_pk(s_pk, w0, sh, 1));
+        uint32_t pkw[PW + 1];
 #pragma unroll
-        for (int j = 2; j + 3 < PW; j += 4)
-          dst[(j + 6) / 4] = make_uint4(gf_cut_pk(s_pk, w0, sh, j), gf_cut_pk(s_pk, w0, sh, j + 1),
-                                        gf_cut_pk(s_pk, w0, sh, j + 2), gf_cut_pk(s_pk, w0, sh, j + 3));
-        if (PW % 4 == 0)
-          dst[(PW + 4) / 4] = make_uint4(gf_cut_pk(s_pk, w0, sh, PW - 2), gf_cut_pk(s_pk, w0, sh, PW - 1), 0u, 0u);
+        for (int j = 0; j < PW; ++j) pkw[j] = gf_cut_pk(s_pk, w0, sh, j);
+        pkw[PW] = 0;
+        gf_entry_store<PW>(my_list + slot_b, (uint32_t)r, e_v1v2, e_todo, pkw);
+      }
+      if (batch_max > lmax) {  // (wave-uniform) batches with longer reads only
+        const unsigned int s1 = gf_wave_append(long1k, ctr + 2);
+        if (long1k) list_long[s1] = (uint32_t)r;
+        const unsigned int s4 = gf_wave_append(long4k, ctr + 3);
+        if (long4k) list_long[n - 1 - (int64_t)s4] = (uint32_t)r;
       }
       r0 += nfit;
     }
@@ -848,39 +902,6 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 // (One kernel doing both kept every wave in the bucket loop for as long as its unluckiest
 // lane: most of its instructions were executed for a handful of lanes.)
 template <int PW>
-__device__ __forceinline__ void gf_entry_load(const GfPipeEntryW<PW>* e, uint32_t& r, uint32_t& v1v2, uint32_t (&m)[4],
-                                              uint32_t (&pk)[PW + 1]) {
-  constexpr int EW = sizeof(GfPipeEntryW<PW>) / 16;
-  uint4 ew[EW];
-  const uint4* src = (const uint4*)e;
-#pragma unroll
-  for (int j = 0; j < EW; ++j) ew[j] = src[j];
-  r = ew[0].x;
-  v1v2 = ew[0].y;
-  m[0] = ew[0].z; m[1] = ew[0].w; m[2] = ew[1].x; m[3] = ew[1].y;
-  pk[0] = ew[1].z;
-  pk[1] = ew[1].w;
-#pragma unroll
-  for (int j = 2; j < PW; ++j) {
-    const uint4 q = ew[(j + 6) / 4];
-    const int k = (j + 6) % 4;
-    pk[j] = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
-  }
-  pk[PW] = 0;
-}
-
-template <int PW>
-__device__ __forceinline__ void gf_entry_store(GfPipeEntryW<PW>* e, uint32_t r, uint32_t v1v2, const uint32_t (&m)[4],
-                                               const uint32_t (&pk)[PW + 1]) {
-  uint4* dst = (uint4*)e;
-  dst[0] = make_uint4(r, v1v2, m[0], m[1]);
-  dst[1] = make_uint4(m[2], m[3], pk[0], pk[1]);
-#pragma unroll
-  for (int j = 2; j + 3 < PW; j += 4) dst[(j + 6) / 4] = make_uint4(pk[j], pk[j + 1], pk[j + 2], pk[j + 3]);
-  if (PW % 4 == 0) dst[(PW + 4) / 4] = make_uint4(pk[PW - 2], pk[PW - 1], 0u, 0u);
-}
-
-template <int PW>
 __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW<PW>* __restrict__ list_b,
                                                          const unsigned int* __restrict__ blk_cnt, int64_t per_block,
                                                          uint8_t* __restrict__ counts,
@@ -893,12 +914,17 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
   for (unsigned int t0 = 0; t0 < nb; t0 += 256) {
     const unsigned int t = t0 + threadIdx.x;
     bool alive = false;
-    uint32_t r = 0, v1v2 = 0, m[4] = {0, 0, 0, 0}, pk[PW + 1];
-    uint32_t pp[4] = {0, 0, 0, 0};  // windows the filter could not rule out
+    constexpr int NT = GfPipeEntryW<PW>::NT;
+    uint32_t r = 0, v1v2 = 0, m[NT], pk[PW + 1];
+    uint32_t pp[NT];  // windows the filter could not rule out
+#pragma unroll
+    for (int k = 0; k < NT; ++k) m[k] = pp[k] = 0;
     if (t < nb) {
       gf_entry_load<PW>(my_list + t, r, v1v2, m, pk);
       const int v1 = (int)(v1v2 & 0xFFu), v2 = (int)((v1v2 >> 8) & 0xFFu);
-      int npos = 0, rem = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);  // not ruled out / not asked yet
+      int npos = 0, rem = 0;  // not ruled out / not asked yet
+#pragma unroll
+      for (int k = 0; k < NT; ++k) rem += __popc(m[k]);
       bool dead = false;
       if (T.bloom_words) {
         // windows 2q and 2q+1 share the 14-mer at bases 4q+2 .. 4q+15: one lookup for both.
@@ -912,7 +938,7 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
             for (int u = 0; u < 4; ++u) {
               const int q = q0 + u;
               const int wbit = (2 * q) & 31, wword = (2 * q) >> 5;
-              both[u] = wword < 4 ? (m[wword] >> wbit) & 3u : 0u;
+              both[u] = wword < NT ? (m[wword] >> wbit) & 3u : 0u;
               const int b0 = 4 * q + 2;  // first base of the shared 14-mer
               const int j = b0 >> 4;
               const uint32_t sh14 = 2u * (uint32_t)(b0 & 15);
@@ -928,7 +954,7 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
               const int cnt = (int)(both[u] & 1u) + (int)(both[u] >> 1);
               rem -= cnt;
               if (both[u] && (word[u] & bits[u]) == bits[u]) {
-                pp[(2 * q) >> 5 < 4 ? (2 * q) >> 5 : 0] |= both[u] << ((2 * q) & 31);
+                pp[(2 * q) >> 5 < NT ? (2 * q) >> 5 : 0] |= both[u] << ((2 * q) & 31);
                 npos += cnt;
               }
             }
@@ -937,7 +963,8 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
           }
         }
       } else {
-        pp[0] = m[0]; pp[1] = m[1]; pp[2] = m[2]; pp[3] = m[3];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) pp[k] = m[k];
         const int left = rem;
         dead = (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
       }
@@ -968,13 +995,15 @@ __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPip
     bool to_full = false;
     uint32_t r = 0;
     if (t < nb) {
-      uint32_t v1v2, p[4], pk[PW + 1];
+      constexpr int NT = GfPipeEntryW<PW>::NT;
+      uint32_t v1v2, p[NT], pk[PW + 1];
       gf_entry_load<PW>(my_list + t, r, v1v2, p, pk);
       const int v1 = (int)(v1v2 & 0xFFu), v2 = (int)((v1v2 >> 8) & 0xFFu);
 #pragma unroll
       for (int j = 0; j <= PW; ++j) s_pk[j * 256 + threadIdx.x] = pk[j];  // the loop indexes the words dynamically
-      uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
-      int left = __popc(p0) + __popc(p1) + __popc(p2) + __popc(p3);
+      int left = 0;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) left += __popc(p[k]);
       int h = 0;
       bool dead = (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
       while (!dead && left > 0) {
@@ -988,13 +1017,21 @@ __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPip
         bool act[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          act[u] = u < need && (p0 | p1 | p2 | p3);
+          uint32_t any = 0;
+#pragma unroll
+          for (int k = 0; k < NT; ++k) any |= p[k];
+          act[u] = u < need && any;
           int w = 0;
-          if (act[u]) {
-            if (p0) { w = __builtin_ctz(p0); p0 &= p0 - 1; }
-            else if (p1) { w = 32 + __builtin_ctz(p1); p1 &= p1 - 1; }
-            else if (p2) { w = 64 + __builtin_ctz(p2); p2 &= p2 - 1; }
-            else { w = 96 + __builtin_ctz(p3); p3 &= p3 - 1; }
+          if (act[u]) {  // lowest window still standing
+            bool taken = false;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+              if (!taken && p[k]) {
+                w = 32 * k + __builtin_ctz(p[k]);
+                p[k] &= p[k] - 1;
+                taken = true;
+              }
+            }
           }
           const int j = w >> 3;
           const uint32_t sh = 4u * (uint32_t)(w & 7);
@@ -1023,19 +1060,17 @@ __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPip
 
 // ---- K_full: the exact wave-per-read kernel over a list of read indices ----
 template <int LCAP, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 8) void gf_k_map_reads_list(GfTable T, const uint8_t* __restrict__ bases,
-                                                                  const int64_t* __restrict__ offsets,
-                                                                  const uint32_t* __restrict__ list,
-                                                                  const unsigned int* __restrict__ n_list,
-                                                                  uint8_t* __restrict__ counts,
-                                                                  gf_seqmatch* __restrict__ matches) {
+__global__ __launch_bounds__(WAVES * 64, LCAP <= 256 ? 8 : (LCAP <= 1024 ? 3 : 1)) void gf_k_map_reads_list(
+    GfTable T, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+    const uint32_t* __restrict__ list, int64_t stride, const unsigned int* __restrict__ n_list,
+    uint8_t* __restrict__ counts, gf_seqmatch* __restrict__ matches) {
   __shared__ GfMapSmem<LCAP> smem[WAVES];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   GfMapSmem<LCAP>& S = smem[wib];
   const unsigned int nl = *n_list;
   for (unsigned int k = blockIdx.x * WAVES + wib; k < nl; k += gridDim.x * WAVES) {
-    const int64_t r = (int64_t)list[k];
+    const int64_t r = (int64_t)list[(int64_t)k * stride];
     const int64_t off0 = offsets[r];
     const int L = (int)(offsets[r + 1] - off0);
     gf_wave_lds_sync();

@@ -155,6 +155,7 @@ static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** 
 struct FlatWs {
   void* list_b;
   uint32_t* list_c;
+  uint32_t* list_long;
   unsigned int* blk_cnt;
   unsigned int* blk_cnt2;
   unsigned int* ctr;
@@ -162,19 +163,22 @@ struct FlatWs {
 struct FlatPlan {
   int nblk;
   int64_t per_block;
-  size_t sz_lb, sz_lc, sz_bc, sz_ctr;
-  size_t bytes() const { return sz_lb + sz_lc + 2 * sz_bc + sz_ctr; }
+  size_t sz_lb, sz_lc, sz_ll, sz_bc, sz_ctr;
+  size_t bytes() const { return sz_lb + sz_lc + sz_ll + 2 * sz_bc + sz_ctr; }
 };
-static FlatPlan flat_plan(int64_t n, int n_cus, bool small) {
+// pw = words per read of the flat kernels (10, 16 or 20); long_reads = the batch may hold reads
+// beyond the flat kernels' limit
+static FlatPlan flat_plan(int64_t n, int n_cus, int pw, bool long_reads) {
   FlatPlan p;
   int blk_mult = 32;
   if (const char* e = getenv("GF_NBLK_MULT")) blk_mult = std::max(1, atoi(e));  // experiments
   p.nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)n_cus * blk_mult));
   p.per_block = (n + p.nblk - 1) / p.nblk;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t esz = small ? sizeof(GfPipeEntryW<10>) : sizeof(GfPipeEntryW<16>);
+  const size_t esz = pw == 10 ? sizeof(GfPipeEntryW<10>) : (pw == 16 ? sizeof(GfPipeEntryW<16>) : sizeof(GfPipeEntryW<20>));
   p.sz_lb = al((size_t)n * esz);
   p.sz_lc = al((size_t)n * sizeof(uint32_t));
+  p.sz_ll = long_reads ? al((size_t)n * sizeof(uint32_t)) : 0;
   p.sz_bc = al((size_t)p.nblk * sizeof(unsigned int));
   p.sz_ctr = 256;
   return p;
@@ -183,25 +187,28 @@ static FlatWs flat_carve(uint8_t* wp, const FlatPlan& p) {
   FlatWs w;
   w.list_b = (void*)wp; wp += p.sz_lb;
   w.list_c = (uint32_t*)wp; wp += p.sz_lc;
+  w.list_long = (uint32_t*)wp; wp += p.sz_ll;
   w.blk_cnt = (unsigned int*)wp; wp += p.sz_bc;
   w.blk_cnt2 = (unsigned int*)wp; wp += p.sz_bc;
   w.ctr = (unsigned int*)wp;
   return w;
 }
-// ev[0..4] (optional): stage boundaries
+// ev[0..4] (optional): stage boundaries.  lmax = longest read of the flat kernels in this call,
+// batch_max = the caller's limit: reads in between go to the wave-per-read kernels of the
+// longer classes (LDS footprints for 1024 and 4096 bases) through a list.
 template <int PW>
 static int launch_flat(const gf_index* idx, hipStream_t st, const uint8_t* bases, const int64_t* offsets, int64_t n,
-                       int lmax, int mark, uint8_t* counts, gf_seqmatch* matches, const FlatWs& w, const FlatPlan& p,
-                       hipEvent_t* ev) {
+                       int lmax, int batch_max, uint8_t* counts, gf_seqmatch* matches, const FlatWs& w,
+                       const FlatPlan& p, hipEvent_t* ev) {
   GF_HIP(hipMemsetAsync(w.ctr, 0, 64, st));
   if (ev) GF_HIP(hipEventRecord(ev[0], st));
   // Seed+verify is bound by L2-missing requests, not by waves in flight: four blocks per CU
   // (40 KB of LDS each, padded with dynamic LDS) measured 2.5 % faster than the six its
   // registers allow.
-  size_t pad_lds = 24000;
+  size_t pad_lds = PW == 10 ? 24000 : 0;
   if (const char* e = getenv("GF_SV_PAD_LDS")) pad_lds = (size_t)atoi(e);  // experiments
-  hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(p.nblk), dim3(256), pad_lds, st, idx->table, bases, offsets, n, lmax,
-                     mark, counts, (GfPipeEntryW<PW>*)w.list_b, w.blk_cnt, p.per_block, w.ctr);
+  hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(p.nblk), dim3(256), pad_lds, st, idx->table, bases, offsets, n,
+                     lmax, batch_max, counts, (GfPipeEntryW<PW>*)w.list_b, w.blk_cnt, p.per_block, w.list_long, w.ctr);
   if (ev) GF_HIP(hipEventRecord(ev[1], st));
   hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(p.nblk), dim3(256), 0, st, idx->table, (GfPipeEntryW<PW>*)w.list_b,
                      w.blk_cnt, p.per_block, counts, w.blk_cnt2);
@@ -209,8 +216,19 @@ static int launch_flat(const gf_index* idx, hipStream_t st, const uint8_t* bases
   hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(p.nblk), dim3(256), 0, st, idx->table,
                      (const GfPipeEntryW<PW>*)w.list_b, w.blk_cnt2, p.per_block, counts, w.list_c, w.ctr);
   if (ev) GF_HIP(hipEventRecord(ev[3], st));
-  hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(idx->n_cus * 8), dim3(256), 0, st, idx->table, bases, offsets,
-                     w.list_c, w.ctr + 1, counts, matches);
+  if (PW <= 16)
+    hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(idx->n_cus * 8), dim3(256), 0, st, idx->table, bases, offsets,
+                       w.list_c, (int64_t)1, w.ctr + 1, counts, matches);
+  else  // survivors of up to 320 bases
+    hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4>), dim3(idx->n_cus * 4), dim3(256), 0, st, idx->table, bases,
+                       offsets, w.list_c, (int64_t)1, w.ctr + 1, counts, matches);
+  if (batch_max > lmax) {
+    hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4>), dim3(idx->n_cus * 4), dim3(256), 0, st, idx->table, bases,
+                       offsets, w.list_long, (int64_t)1, w.ctr + 2, counts, matches);
+    if (batch_max > 1024)
+      hipLaunchKernelGGL((gf_k_map_reads_list<4096, 2>), dim3(idx->n_cus * 4), dim3(128), 0, st, idx->table, bases,
+                         offsets, w.list_long + (n - 1), (int64_t)-1, w.ctr + 3, counts, matches);
+  }
   GF_HIP(hipGetLastError());
   if (ev) GF_HIP(hipEventRecord(ev[4], st));
   return GF_OK;
@@ -475,24 +493,22 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
   // small-LDS kernel with the seed+verify first pass.
   const int top = max_read_len <= 256 ? 0 : (max_read_len <= 1024 ? 1 : 2);
   if (idx->map_variant == 0) {
-    // flat pipeline, K_pack fused into K_seedverify through LDS
-    const bool small = max_read_len <= 160;
-    const int lmax = top == 0 ? max_read_len : 256;
-    const int mark = top == 0 ? 1 : 0;
+    // flat pipeline (packing fused into seed+verify through LDS) for reads of up to 320 bases —
+    // that covers the merged reads of 2 x 150 — and lists for the wave-per-read kernels of longer reads
+    const int lmax = std::min<int>(max_read_len, 320);
+    const int pw = lmax <= 160 ? 10 : (lmax <= 256 ? 16 : 20);
     std::lock_guard<std::mutex> ws_lock(mix->ws_mu);  // held until this call's launches are queued
-    {
-      const FlatPlan p = flat_plan(n, idx->n_cus, small);
-      void* ws_base = nullptr;
-      int wrc = acquire_workspace(mix, st, p.bytes(), &ws_base);
-      if (wrc != GF_OK) return wrc;
-      const FlatWs w = flat_carve((uint8_t*)ws_base, p);
-      wrc = small ? launch_flat<10>(idx, st, bases, offsets, n, lmax, mark, counts, matches, w, p,
-                                    prof ? mix->ev_stage : nullptr)
-                  : launch_flat<16>(idx, st, bases, offsets, n, lmax, mark, counts, matches, w, p,
-                                    prof ? mix->ev_stage : nullptr);
-      if (wrc != GF_OK) return wrc;
-      if (prof) mix->stages_recorded = true;
-    }
+    const FlatPlan p = flat_plan(n, idx->n_cus, pw, max_read_len > lmax);
+    void* ws_base = nullptr;
+    int wrc = acquire_workspace(mix, st, p.bytes(), &ws_base);
+    if (wrc != GF_OK) return wrc;
+    const FlatWs w = flat_carve((uint8_t*)ws_base, p);
+    hipEvent_t* ev = prof ? mix->ev_stage : nullptr;
+    wrc = pw == 10   ? launch_flat<10>(idx, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
+          : pw == 16 ? launch_flat<16>(idx, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
+                     : launch_flat<20>(idx, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev);
+    if (wrc != GF_OK) return wrc;
+    if (prof) mix->stages_recorded = true;
   } else if (idx->map_variant == 3) {
     // flat pipeline with a separate K_pack (kept for A/B measurements against the fused form)
     const bool small = max_read_len <= 160;
@@ -554,7 +570,7 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     }
     if (prof) GF_HIP(hipEventRecord(mix->ev_stage[3], st));
     hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(g_full), dim3(256), 0, st, idx->table, bases, offsets,
-                       list_c, ctr + 1, counts, matches);
+                       list_c, (int64_t)1, ctr + 1, counts, matches);
     GF_HIP(hipGetLastError());
     if (prof) {
       GF_HIP(hipEventRecord(mix->ev_stage[4], st));
@@ -570,13 +586,13 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
       hipLaunchKernelGGL((gf_k_map_reads_short<W, 1>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
                          n, top == 0 ? 1 : 0, counts, matches);
   }
-  if (top >= 1) {
+  if (top >= 1 && idx->map_variant != 0) {
     constexpr int W = 4;
     int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 4 * 2);
     hipLaunchKernelGGL((gf_k_map_reads<1024, W, 0>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
                        n, 256, top == 1 ? 1 : 0, counts, matches);
   }
-  if (top >= 2) {
+  if (top >= 2 && idx->map_variant != 0) {
     constexpr int W = 2;
     int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 2 * 2);
     hipLaunchKernelGGL((gf_k_map_reads<4096, W, 0>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,

@@ -250,7 +250,7 @@ def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, vari
             assert [(int(ctg[j, t]), int(pos[j, t])) for t in range(n)] == sites
     synth.MIXES["TEST"] = (0.2, 0.5, 0.3)
     total_hits = 0
-    for L in (150, 100, 251):
+    for L in (150, 100, 251, 272, 320):  # 272 = two merged 151-base reads; 320 = the flat kernels' limit
         rb = synth.make_reads(genes, n_reads // 3, read_len=L, mix="TEST", seed=77 + L)
         bases = rb.bases.numpy()
         offsets = rb.offsets.numpy()
