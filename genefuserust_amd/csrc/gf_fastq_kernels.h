@@ -105,6 +105,30 @@ __device__ __forceinline__ void gf_fq_line(const int64_t* __restrict__ nl_pos, i
   end = k < n_newlines ? nl_pos[k] : n_bytes;
 }
 
+// One wavefront copies n bytes from src to dst (any alignments): whole destination dwords
+// are assembled from two aligned source dwords with v_alignbyte, the few bytes before the
+// first and after the last whole dword are copied singly.  An aligned dword never crosses a
+// page, and every dword loaded holds at least one byte of the line, so nothing outside the
+// text's pages is touched.
+__device__ __forceinline__ void gf_fq_copy_line(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, int n,
+                                                int lane) {
+  const int head = (int)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u);  // bytes before the first aligned dword
+  const int h = head < n ? head : n;
+  const int ndw = (n - h) >> 2;
+  const int tail0 = h + 4 * ndw;
+  if (lane < h) dst[lane] = src[lane];
+  if (lane >= 32 && lane - 32 < n - tail0) dst[tail0 + lane - 32] = src[tail0 + lane - 32];
+  uint32_t* d4 = (uint32_t*)(dst + h);
+  const uint8_t* s0 = src + h;
+  const uint32_t sh = (uint32_t)((uintptr_t)s0 & 3u);
+  const uint32_t* s4 = (const uint32_t*)(s0 - sh);
+  for (int k = lane; k < ndw; k += 64) {
+    const uint32_t lo = s4[k];
+    const uint32_t hi = sh ? s4[k + 1] : 0u;
+    d4[k] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+  }
+}
+
 #define GF_FQ_RTILE 256  // records per block of the two record kernels: one per thread
 
 // sequence length of every record, summed per tile of 256 records
@@ -125,7 +149,7 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_lens(const int64_t* __res
 }
 
 // offsets[] of the records, then the sequence and quality lines copied a wavefront per
-// record, 64 bytes per step.  A quality line shorter than its sequence is padded with '!'
+// record, 256 bytes per step.  A quality line shorter than its sequence is padded with '!'
 // (Phred 0), a longer one is cut: both are counted in *n_bad (the reference does not check,
 // and its fast_merge would panic on the short ones).
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __restrict__ text,
@@ -161,13 +185,67 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __r
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int in_tile = (int)((n_rec - t0) < GF_FQ_RTILE ? (n_rec - t0) : GF_FQ_RTILE);
-  for (int i = wave; i < in_tile; i += GF_CTHREADS / 64) {
-    const int64_t src = s_ss[i], qsrc = s_qs[i], dst = s_dst[i];
-    const int ln = s_len[i], ql = s_qlen[i];
-    for (int k = lane; k < ln; k += 64) {
-      if (dst + k < cap_bytes) {
-        bases[dst + k] = text[src + k];
-        quals[dst + k] = k < ql ? text[qsrc + k] : (uint8_t)'!';
+  // each wavefront takes records wave, wave+4, ...; four records per round so that their
+  // loads are in flight together (a record is one load-store round trip otherwise)
+  for (int i0 = wave; i0 < in_tile; i0 += 4 * (GF_CTHREADS / 64)) {
+    bool simple[4];
+    uint32_t slo[4], shi[4], qlo[4], qhi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * (GF_CTHREADS / 64);
+      simple[u] = false;
+      if (i < in_tile) {
+        const int ln = s_len[i];
+        const int64_t dst = s_dst[i];
+        // the common shape: quality as long as the sequence, at most 64 whole dwords per line
+        simple[u] = s_qlen[i] == ln && ln <= 256 && dst + ln <= cap_bytes;
+        if (simple[u]) {
+          // bases and quals share dst, hence the split into head bytes, dwords and tail bytes
+          const int head = (int)((4u - (uint32_t)((uintptr_t)(bases + dst) & 3u)) & 3u);
+          const int h = head < ln ? head : ln;
+          const int ndw = (ln - h) >> 2;
+          if (lane < ndw) {
+            const uint8_t* a = text + s_ss[i] + h + 4 * lane;
+            const uint8_t* b = text + s_qs[i] + h + 4 * lane;
+            const uint32_t sa = (uint32_t)((uintptr_t)a & 3u), sb = (uint32_t)((uintptr_t)b & 3u);
+            slo[u] = *(const uint32_t*)(a - sa);
+            shi[u] = sa ? *(const uint32_t*)(a - sa + 4) : 0u;
+            qlo[u] = *(const uint32_t*)(b - sb);
+            qhi[u] = sb ? *(const uint32_t*)(b - sb + 4) : 0u;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * (GF_CTHREADS / 64);
+      if (i >= in_tile) continue;
+      const int64_t dst = s_dst[i];
+      const int ln = s_len[i], ql = s_qlen[i];
+      if (dst + ln > cap_bytes) continue;  // (the caller's buffers are too small: offsets still tell how much is needed)
+      const uint8_t* ssrc = text + s_ss[i];
+      const uint8_t* qsrc = text + s_qs[i];
+      if (simple[u]) {
+        const int head = (int)((4u - (uint32_t)((uintptr_t)(bases + dst) & 3u)) & 3u);
+        const int h = head < ln ? head : ln;
+        const int ndw = (ln - h) >> 2;
+        const int tail0 = h + 4 * ndw;
+        if (lane < ndw) {
+          const uint32_t sa = (uint32_t)((uintptr_t)(ssrc + h) & 3u), sb = (uint32_t)((uintptr_t)(qsrc + h) & 3u);
+          ((uint32_t*)(bases + dst + h))[lane] = __builtin_amdgcn_alignbyte(shi[u], slo[u], sa);
+          ((uint32_t*)(quals + dst + h))[lane] = __builtin_amdgcn_alignbyte(qhi[u], qlo[u], sb);
+        }
+        if (lane < h) {
+          bases[dst + lane] = ssrc[lane];
+          quals[dst + lane] = qsrc[lane];
+        }
+        if (lane >= 32 && lane - 32 < ln - tail0) {
+          bases[dst + tail0 + lane - 32] = ssrc[tail0 + lane - 32];
+          quals[dst + tail0 + lane - 32] = qsrc[tail0 + lane - 32];
+        }
+      } else {
+        gf_fq_copy_line(bases + dst, ssrc, ln, lane);
+        for (int k = lane; k < ln; k += 64) quals[dst + k] = k < ql ? qsrc[k] : (uint8_t)'!';
       }
     }
   }
