@@ -15,15 +15,13 @@
 //     runs on bases alone and touches qualities only for overlaps with <= 2 mismatches;
 //   * in the 2-bit packed form a candidate overlap is tested 16 columns per XOR.
 //
-//   gf_k_pack       (gf_pipe_kernels.h) R1 bytes -> packed stream, coalesced
-//   gf_k_pack_rc    R2 bytes -> packed stream of the whole buffer reversed and complemented:
-//                   rc(R2 of pair p) is a contiguous piece of it, no per-pair reversal
-//   gf_k_merge_find thread per pair: slide R1's packed words past the first 16 bases of
-//                   rc(R2); candidates with <= 2 mismatches there get the full-overlap
-//                   count (still packed) and, with <= 2 in total, the quality test
+//   gf_k_merge_find_stream  thread per pair; each wavefront packs the spans of its next 64
+//                   pairs into LDS tiles, then every lane slides R1's packed words past the
+//                   first 16 bases of rc(R2); candidates with <= 2 mismatches there get the
+//                   full-overlap count (still packed) and, with <= 2 in total, the quality test
 //   gf_k_merge_write wave per merged pair: assembles the merged read and its quality
 // Pairs the packed form cannot decide exactly (a read longer than the kernel's word
-// budget, outside the packed stream, or both reads holding a byte outside A/C/G/T where
+// budget, or both reads holding a byte outside A/C/G/T where
 // 'N' == 'N' could make two such bytes equal) take gf_merge_find_bytes, the plain byte
 // loop.
 #pragma once
@@ -75,173 +73,236 @@ __device__ inline int gf_merge_find_bytes(const uint8_t* s1, const uint8_t* q1, 
   return 0;
 }
 
-// 4 ASCII bases -> 8 code bits and 4 "bad" bits, case-insensitive: valid = ACGTacgt, the
-// bytes whose reverse complement is not 'N' (sequence.rs:22-60).
-__device__ __forceinline__ void gf_convert4_bits_nocase(uint32_t x, uint32_t& code8, uint32_t& bad4) {
-  uint32_t y = (x >> 1) & 0x03030303u;
-  code8 = (y * 0x01041040u) >> 24;
-  uint32_t bad = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    uint32_t b = (x >> (8 * j)) & 0xFFu;
-    uint32_t v = (((b & 0xC0u) == 0x40u) ? 1u : 0u) & (0x0010008Au >> (b & 31u));
-    bad |= (v ^ 1u) << j;
-  }
-  bad4 = bad;
-}
-
-// chunks of 16 bytes the packed stream of a buffer covers (same formula in every kernel)
-__device__ __forceinline__ uint64_t gf_stream_chunks(const uint8_t* bases, const int64_t* offsets, int64_t n,
-                                                     uint64_t cap_chunks) {
-  const uintptr_t a0 = gf_stream_origin(bases, offsets);
-  const uintptr_t end = (uintptr_t)(bases + offsets[n]);
-  uint64_t chunks = end > a0 ? (uint64_t)((end - a0 + 15) >> 4) : 0;
-  return chunks > cap_chunks ? cap_chunks : chunks;
-}
-
-// ---- K_pack_rc: thread per 16 bytes of R2; word (chunks-1-t) of the output = the chunk's
-// bases reversed and complemented (A0 C1 T2 G3: complement = code ^ 2) ----
-__global__ __launch_bounds__(256) void gf_k_pack_rc(const uint8_t* __restrict__ bases,
-                                                    const int64_t* __restrict__ offsets, int64_t n,
-                                                    uint64_t cap_chunks, uint32_t* __restrict__ pkg,
-                                                    uint16_t* __restrict__ ivg16) {
-  const uintptr_t a0 = gf_stream_origin(bases, offsets);
-  const uint64_t chunks = gf_stream_chunks(bases, offsets, n, cap_chunks);
-  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < chunks;
-       t += (uint64_t)gridDim.x * blockDim.x) {
-    const uint4 q = *(const uint4*)(a0 + 16 * t);
-    uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
-    gf_convert4_bits_nocase(q.x, c0, b0);
-    gf_convert4_bits_nocase(q.y, c1, b1);
-    gf_convert4_bits_nocase(q.z, c2, b2);
-    gf_convert4_bits_nocase(q.w, c3, b3);
-    const uint32_t c = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-    const uint32_t b = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
-    uint32_t x = __brev(c);  // fields reversed, and the two bits of each field swapped
-    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
-    pkg[chunks - 1 - t] = x ^ 0xAAAAAAAAu;
-    ivg16[chunks - 1 - t] = (uint16_t)(__brev(b) >> 16);
-  }
-}
-
 // even-bit mask of the bases below L in word j of a read
 __device__ __forceinline__ uint32_t gf_len_mask2(int L, int j) {
   const int k = L - 16 * j;
   return k >= 16 ? 0x55555555u : (k <= 0 ? 0u : (((1u << (2 * k)) - 1u) & 0x55555555u));
 }
 
-// ---- K_merge_find: thread per pair ----
-template <int PW>
-__global__ __launch_bounds__(256) void gf_k_merge_find(GfStream S1, GfStream S2, const uint8_t* __restrict__ l_bases,
-                                                       const uint8_t* __restrict__ l_quals,
-                                                       const int64_t* __restrict__ l_off,
-                                                       const uint8_t* __restrict__ r_bases,
-                                                       const uint8_t* __restrict__ r_quals,
-                                                       const int64_t* __restrict__ r_off, int64_t n,
-                                                       int32_t* __restrict__ out_len, int32_t* __restrict__ out_diff) {
-  // R1's words, indexed dynamically by the full-overlap count ([word][thread]: own column only)
-  __shared__ uint32_t s_a[(PW + 1) * 256];
-  __shared__ uint32_t s_ia[(PW + 1) * 256];
-  const uintptr_t a1 = gf_stream_origin(l_bases, l_off);
-  const uintptr_t a2 = gf_stream_origin(r_bases, r_off);
-  const uint64_t chunks2 = gf_stream_chunks(r_bases, r_off, n, S2.cap_bases >> 4);
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t lo1 = l_off[p], lo2 = r_off[p];
-    const int64_t len1_64 = l_off[p + 1] - lo1, len2_64 = r_off[p + 1] - lo2;
-    const int64_t lim64 = len1_64 < len2_64 ? len1_64 : len2_64;
-    if (lim64 < GF_MERGE_MIN_OVERLAP) {
-      out_len[p] = 0;
-      out_diff[p] = 0;
-      continue;
+// ---- K_merge_find_stream: thread per pair, packing folded in ----
+// As in gf_k_seedverify_stream, consecutive reads are consecutive bytes: each wavefront
+// converts the spans of its next 64 pairs — one of R1, one of R2 — to the packed form with
+// coalesced, non-temporal 16-byte loads straight into two LDS tiles of its own, and every
+// lane cuts its pair's words out of them.  rc(R2) is read off the forward tile: word j of
+// the reverse complement is the field-reversed, complemented word that ends 16j bases
+// before the end of R2.  No packed streams in HBM, no packing kernels.
+
+// like gf_convert16, but valid = ACGTacgt (the bytes whose reverse complement is not 'N')
+__device__ __forceinline__ void gf_convert16_nocase(const uint4& q, uint32_t& code32, uint32_t& bad16) {
+  const uint32_t y0 = (q.x >> 1) & 0x03030303u, y1 = (q.y >> 1) & 0x03030303u;
+  const uint32_t y2 = (q.z >> 1) & 0x03030303u, y3 = (q.w >> 1) & 0x03030303u;
+  const uint32_t d0 = (q.x & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, y0);
+  const uint32_t d1 = (q.y & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, y1);
+  const uint32_t d2 = (q.z & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, y2);
+  const uint32_t d3 = (q.w & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, y3);
+  code32 = ((y0 * 0x01041040u) >> 24) | (((y1 * 0x01041040u) >> 24) << 8) | (((y2 * 0x01041040u) >> 24) << 16) |
+           (((y3 * 0x01041040u) >> 24) << 24);
+  bad16 = 0;
+  if (d0 | d1 | d2 | d3) {
+    const uint32_t n0 = (((d0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d0) & 0x80808080u;
+    const uint32_t n1 = (((d1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d1) & 0x80808080u;
+    const uint32_t n2 = (((d2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d2) & 0x80808080u;
+    const uint32_t n3 = (((d3 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d3) & 0x80808080u;
+    bad16 = (((n0 >> 7) * 0x00204081u) >> 21 & 0xFu) | ((((n1 >> 7) * 0x00204081u) >> 21 & 0xFu) << 4) |
+            ((((n2 >> 7) * 0x00204081u) >> 21 & 0xFu) << 8) | ((((n3 >> 7) * 0x00204081u) >> 21 & 0xFu) << 12);
+  }
+}
+
+// 16 2-bit fields of x in reverse order
+__device__ __forceinline__ uint32_t gf_field_reverse_dev(uint32_t x) {
+  x = __brev(x);
+  return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+
+// Word j of rc(R2) from the forward tile: bases [end - 16(j+1), end - 16j) of the stream,
+// reversed and complemented; `end` = stream position one past R2's last base.  The tile
+// keeps 16 bases of slack in front (data starts at stream position 16), so the position
+// never goes negative; bases before R2's first are masked by the caller's length masks.
+__device__ __forceinline__ uint32_t gf_rc_word(const uint32_t* s_pk, uint32_t end, int j) {
+  const uint32_t p = end - 16u * (uint32_t)(j + 1);
+  const uint32_t w = __builtin_amdgcn_alignbit(s_pk[(p >> 4) + 1], s_pk[p >> 4], 2u * (p & 15u));
+  return gf_field_reverse_dev(w) ^ 0xAAAAAAAAu;
+}
+// the same for the "unusable base" flags (1 bit per base in the tile), returned at the even bits
+__device__ __forceinline__ uint32_t gf_rc_flags(const uint32_t* s_iv, uint32_t end, int j) {
+  const uint32_t p = end - 16u * (uint32_t)(j + 1);
+  const uint32_t b = __builtin_amdgcn_alignbit(s_iv[(p >> 5) + 1], s_iv[p >> 5], p & 31u) & 0xFFFFu;
+  return gf_spread16(__brev(b) >> 16);
+}
+
+template <int PW, bool NOCASE>
+__device__ __forceinline__ void gf_stage_tile(const uint4* __restrict__ src, uint32_t chunks, uint32_t* s_pk,
+                                              uint32_t* s_iv, int lane, int lead_chunks) {
+  constexpr int TILE_CHUNKS = 64 * PW + 1;
+  constexpr int NLOAD = (TILE_CHUNKS + 63) / 64;
+  uint4 q[NLOAD];
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const uint32_t c = (uint32_t)lane + 64u * (uint32_t)k;
+    const gf_u32x4 t = __builtin_nontemporal_load((const gf_u32x4*)(src + (c < chunks ? c : chunks - 1)));
+    q[k] = make_uint4(t.x, t.y, t.z, t.w);
+  }
+#pragma unroll
+  for (int k = 0; k < NLOAD; ++k) {
+    const uint32_t c = (uint32_t)lane + 64u * (uint32_t)k;
+    uint32_t code32, bad16;
+    if (NOCASE) gf_convert16_nocase(q[k], code32, bad16);
+    else gf_convert16(q[k], code32, bad16);
+    if (c < chunks) {
+      s_pk[c + lead_chunks] = code32;
+      ((uint16_t*)s_iv)[c + lead_chunks] = (uint16_t)bad16;
     }
-    const uint8_t* s1 = l_bases + lo1;
-    const uint8_t* q1 = l_quals + lo1;
-    const uint8_t* s2 = r_bases + lo2;
-    const uint8_t* q2 = r_quals + lo2;
-    const uint64_t pos1 = (uint64_t)((uintptr_t)s1 - a1);
-    const uint64_t x0 = (uint64_t)((uintptr_t)s2 - a2);  // R2's first byte in its buffer's stream
-    bool bytes_path = len1_64 > 16 * PW || len2_64 > 16 * PW || pos1 + (uint64_t)len1_64 + 64 > S1.cap_bases ||
-                      x0 + (uint64_t)len2_64 > 16 * chunks2;
-    int found = 0, diff = 0;
-    const int len1 = (int)len1_64, len2 = (int)len2_64;
-    if (!bytes_path) {
-      const uint64_t pos2 = 16 * chunks2 - (x0 + (uint64_t)len2);  // rc(R2) in the reversed stream
-      uint32_t A[PW], IA[PW], B[PW], IB[PW];
-      gf_load_read_words<PW>(S1, pos1, len1, A, IA);
-      gf_load_read_words<PW>(S2, pos2, len2, B, IB);
-      uint32_t anyA = 0, anyB = 0;
-#pragma unroll
-      for (int j = 0; j < PW; ++j) {
-        anyA |= IA[j] & gf_len_mask2(len1, j);
-        anyB |= IB[j] & gf_len_mask2(len2, j);
-        s_a[j * 256 + threadIdx.x] = A[j];
-        s_ia[j * 256 + threadIdx.x] = IA[j];
+  }
+}
+
+#ifndef GF_MF_WAVES_PER_SIMD
+#define GF_MF_WAVES_PER_SIMD 4
+#endif
+template <int PW>
+__global__ __launch_bounds__(256, PW <= 10 ? GF_MF_WAVES_PER_SIMD : 3) void gf_k_merge_find_stream(const uint8_t* __restrict__ l_bases,
+                                                              const uint8_t* __restrict__ l_quals,
+                                                              const int64_t* __restrict__ l_off,
+                                                              const uint8_t* __restrict__ r_bases,
+                                                              const uint8_t* __restrict__ r_quals,
+                                                              const int64_t* __restrict__ r_off, int64_t n,
+                                                              int32_t* __restrict__ out_len,
+                                                              int32_t* __restrict__ out_diff) {
+  constexpr int TILE_BYTES = 64 * 16 * PW;
+  constexpr int TILE_CHUNKS = TILE_BYTES / 16 + 1;
+  constexpr int PK_WORDS = TILE_CHUNKS + PW + 4;           // +1 chunk of slack in front of R2's tile
+  constexpr int IV_WORDS = (TILE_CHUNKS + PW + 4) / 2 + 2;
+  __shared__ uint32_t s_pk1_all[4][PK_WORDS], s_pk2_all[4][PK_WORDS];
+  __shared__ uint32_t s_iv1_all[4][IV_WORDS], s_iv2_all[4][IV_WORDS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t* s_pk1 = s_pk1_all[wave];
+  uint32_t* s_pk2 = s_pk2_all[wave];
+  uint32_t* s_iv1 = s_iv1_all[wave];
+  uint32_t* s_iv2 = s_iv2_all[wave];
+  if (lane == 0) {  // the slack in front of R2's tile: never used unmasked, but never garbage either
+    s_pk2[0] = 0;
+    s_iv2[0] = 0;
+  }
+  const int64_t n_groups = (n + 63) / 64;
+  for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < n_groups; g += (int64_t)gridDim.x * 4) {
+    const int64_t g0 = g * 64, g1 = g0 + 64 < n ? g0 + 64 : n;
+    int64_t p0 = g0;
+    while (p0 < g1) {
+      // the pairs p0 .. p0+nfit-1 (a prefix of the group) fit in both tiles
+      const int64_t base1 = l_off[p0], base2 = r_off[p0];
+      const uint8_t* q01 = l_bases + base1;
+      const uint8_t* q02 = r_bases + base2;
+      const uint32_t mis1 = (uint32_t)((uintptr_t)q01 & 15u), mis2 = (uint32_t)((uintptr_t)q02 & 15u);
+      const int64_t p = p0 + lane;
+      int64_t lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
+      if (p < g1) {
+        lo1 = l_off[p]; hi1 = l_off[p + 1];
+        lo2 = r_off[p]; hi2 = r_off[p + 1];
       }
-      s_a[PW * 256 + threadIdx.x] = 0;
-      s_ia[PW * 256 + threadIdx.x] = 0x55555555u;
-      // a byte outside A/C/G/T in R1 and one outside ACGTacgt in R2 could be equal ('N' vs the
-      // 'N' of the reverse complement): only the byte loop knows
-      bytes_path = anyA && anyB;
-      if (!bytes_path) {
-        const int lim = len1 < len2 ? len1 : len2;
-        const int o_hi = len1 - GF_MERGE_MIN_OVERLAP, o_lo = len1 - lim;  // offsets to try, high to low
-        const uint32_t b0 = B[0], ib0 = IB[0];
-        bool done = false;
+      const bool fits = p < g1 && (uint64_t)(hi1 - base1) + mis1 <= (uint64_t)TILE_BYTES &&
+                        (uint64_t)(hi2 - base2) + mis2 <= (uint64_t)TILE_BYTES;
+      int nfit = __popcll(__ballot(fits));
+      const bool oversize = nfit == 0;  // a read larger than a tile: the byte loop for this pair
+      if (oversize) nfit = 1;
+      gf_wave_lds_sync();  // the previous tile's LDS reads are done
+      if (!oversize) {
+        const uint32_t chunks1 = (uint32_t)((l_off[p0 + nfit] - base1) + mis1 + 15) >> 4;
+        const uint32_t chunks2 = (uint32_t)((r_off[p0 + nfit] - base2) + mis2 + 15) >> 4;
+        if (chunks1) gf_stage_tile<PW, false>((const uint4*)(q01 - mis1), chunks1, s_pk1, s_iv1, lane, 0);
+        __builtin_amdgcn_sched_barrier(0);  // one tile's loads in registers at a time
+        if (chunks2) gf_stage_tile<PW, true>((const uint4*)(q02 - mis2), chunks2, s_pk2, s_iv2, lane, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      gf_wave_lds_sync();
+      if (lane < nfit) {
+        const int64_t len1_64 = hi1 - lo1, len2_64 = hi2 - lo2;
+        const int64_t lim64 = len1_64 < len2_64 ? len1_64 : len2_64;
+        int found = 0, diff = 0;
+        if (lim64 >= GF_MERGE_MIN_OVERLAP) {
+          const uint8_t* s1 = l_bases + lo1;
+          const uint8_t* q1 = l_quals + lo1;
+          const uint8_t* s2 = r_bases + lo2;
+          const uint8_t* q2 = r_quals + lo2;
+          bool bytes_path = oversize || len1_64 > 16 * PW || len2_64 > 16 * PW;
+          const int len1 = (int)len1_64, len2 = (int)len2_64;
+          if (!bytes_path) {
+            const uint32_t pos1 = (uint32_t)(lo1 - base1) + mis1;
+            const uint32_t end2 = (uint32_t)(hi2 - base2) + mis2 + 16u;  // one past R2's last base (+ the slack chunk)
+            const uint32_t w1 = pos1 >> 4, sh1 = 2u * (pos1 & 15u);
+            uint32_t A[PW], IA[PW];
+            uint32_t anyA = 0, anyB = 0;
 #pragma unroll
-        for (int j = PW - 1; j >= 0; --j) {
-          const uint32_t alo = A[j], ahi = j + 1 < PW ? A[j + 1] : 0u;
-          const uint32_t ilo = IA[j], ihi = j + 1 < PW ? IA[j + 1] : 0x55555555u;
-          if (16 * j <= o_hi && 16 * j + 15 >= o_lo) {
-            for (int s = 15; s >= 0; --s) {
-              const int o = 16 * j + s;
-              if (done || o > o_hi || o < o_lo) continue;
-              // first 16 columns: R1 bases o..o+15 against rc(R2) bases 0..15
-              const uint32_t w = __builtin_amdgcn_alignbit(ahi, alo, 2u * (uint32_t)s);
-              const uint32_t iw = __builtin_amdgcn_alignbit(ihi, ilo, 2u * (uint32_t)s);
-              const uint32_t x = w ^ b0;
-              const uint32_t m = ((x | (x >> 1)) | iw | ib0) & 0x55555555u;
-              if (__popc(m) > 2) continue;
-              // all columns of this overlap, 16 per word
-              const int olen = len1 - o;
-              int cnt = 0, c0 = -1, c1 = -1;
+            for (int j = 0; j < PW; ++j) {
+              A[j] = gf_cut_pk(s_pk1, w1, sh1, j);
+              IA[j] = gf_cut_iv(s_iv1, pos1, len1, j);
+              anyA |= IA[j] & gf_len_mask2(len1, j);
+              if (16 * j < len2) anyB |= gf_rc_flags(s_iv2, end2, j) & gf_len_mask2(len2, j);
+            }
+            // a byte outside A/C/G/T in R1 and one outside ACGTacgt in R2 could be equal ('N' vs the
+            // 'N' of the reverse complement): only the byte loop knows
+            bytes_path = anyA && anyB;
+            if (!bytes_path) {
+              const int lim = len1 < len2 ? len1 : len2;
+              const int o_hi = len1 - GF_MERGE_MIN_OVERLAP, o_lo = len1 - lim;  // offsets to try, high to low
+              const uint32_t b0 = gf_rc_word(s_pk2, end2, 0), ib0 = gf_rc_flags(s_iv2, end2, 0);
+              bool done = false;
 #pragma unroll
-              for (int jj = 0; jj < PW; ++jj) {
-                const uint32_t cm = gf_len_mask2(olen, jj);
-                if (cm) {
-                  const int pos = o + 16 * jj;
-                  const int wi = pos >> 4;
-                  const uint32_t sh = 2u * (uint32_t)(pos & 15);
-                  const uint32_t ww = __builtin_amdgcn_alignbit(s_a[(wi + 1) * 256 + threadIdx.x],
-                                                                s_a[wi * 256 + threadIdx.x], sh);
-                  const uint32_t iww = __builtin_amdgcn_alignbit(s_ia[(wi + 1) * 256 + threadIdx.x],
-                                                                 s_ia[wi * 256 + threadIdx.x], sh);
-                  const uint32_t xx = ww ^ B[jj];
-                  uint32_t mm = ((xx | (xx >> 1)) | iww | IB[jj]) & cm;
-                  cnt += __popc(mm);
-                  while (mm && c1 < 0) {
-                    const int col = 16 * jj + (__builtin_ctz(mm) >> 1);
-                    if (c0 < 0) c0 = col; else c1 = col;
-                    mm &= mm - 1;
+              for (int j = PW - 1; j >= 0; --j) {
+                const uint32_t alo = A[j], ahi = j + 1 < PW ? A[j + 1] : 0u;
+                const uint32_t ilo = IA[j], ihi = j + 1 < PW ? IA[j + 1] : 0x55555555u;
+                if (16 * j <= o_hi && 16 * j + 15 >= o_lo) {
+                  for (int s = 15; s >= 0; --s) {
+                    const int o = 16 * j + s;
+                    if (done || o > o_hi || o < o_lo) continue;
+                    // first 16 columns: R1 bases o..o+15 against rc(R2) bases 0..15
+                    const uint32_t w = __builtin_amdgcn_alignbit(ahi, alo, 2u * (uint32_t)s);
+                    const uint32_t iw = __builtin_amdgcn_alignbit(ihi, ilo, 2u * (uint32_t)s);
+                    const uint32_t x = w ^ b0;
+                    const uint32_t m = ((x | (x >> 1)) | iw | ib0) & 0x55555555u;
+                    if (__popc(m) > 2) continue;
+                    // all columns of this overlap, 16 per word, R1's words cut from the tile
+                    const int olen = len1 - o;
+                    int cnt = 0, c0 = -1, c1 = -1;
+#pragma unroll
+                    for (int jj = 0; jj < PW; ++jj) {
+                      const uint32_t cm = gf_len_mask2(olen, jj);
+                      if (cm) {
+                        const uint32_t pa = pos1 + (uint32_t)o + 16u * (uint32_t)jj;
+                        const uint32_t ww = __builtin_amdgcn_alignbit(s_pk1[(pa >> 4) + 1], s_pk1[pa >> 4], 2u * (pa & 15u));
+                        const uint32_t fa = __builtin_amdgcn_alignbit(s_iv1[(pa >> 5) + 1], s_iv1[pa >> 5], pa & 31u) & 0xFFFFu;
+                        const uint32_t xx = ww ^ gf_rc_word(s_pk2, end2, jj);
+                        uint32_t mm = ((xx | (xx >> 1)) | gf_spread16(fa) | gf_rc_flags(s_iv2, end2, jj)) & cm;
+                        cnt += __popc(mm);
+                        while (mm && c1 < 0) {
+                          const int col = 16 * jj + (__builtin_ctz(mm) >> 1);
+                          if (c0 < 0) c0 = col; else c1 = col;
+                          mm &= mm - 1;
+                        }
+                      }
+                    }
+                    if (cnt > 2) continue;
+                    bool ok = true;
+                    if (c0 >= 0) ok = gf_lowq_pair(q1[o + c0], q2[len2 - 1 - c0]);
+                    if (ok && c1 >= 0) ok = gf_lowq_pair(q1[o + c1], q2[len2 - 1 - c1]);
+                    if (ok) {
+                      found = olen;
+                      diff = cnt;
+                      done = true;
+                    }
                   }
                 }
               }
-              if (cnt > 2) continue;
-              bool ok = true;
-              if (c0 >= 0) ok = gf_lowq_pair(q1[o + c0], q2[len2 - 1 - c0]);
-              if (ok && c1 >= 0) ok = gf_lowq_pair(q1[o + c1], q2[len2 - 1 - c1]);
-              if (ok) {
-                found = olen;
-                diff = cnt;
-                done = true;
-              }
             }
           }
+          if (bytes_path) found = gf_merge_find_bytes(s1, q1, len1, s2, q2, len2, diff);
+          out_len[p] = found ? len1 - found + len2 : 0;
+        } else {
+          out_len[p] = 0;
         }
+        out_diff[p] = diff;
       }
+      p0 += nfit;
     }
-    if (bytes_path) found = gf_merge_find_bytes(s1, q1, len1, s2, q2, len2, diff);
-    out_len[p] = found ? len1 - found + len2 : 0;
-    out_diff[p] = diff;
   }
 }
 

@@ -926,7 +926,6 @@ int gf_fast_merge_find_device(const gf_index* idx, const void* d_l_bases, const 
       !d_out_diff)
     return fail(GF_ERR_ARG, "null device pointer");
   DeviceGuard guard(idx->device);
-  gf_index* mix = const_cast<gf_index*>(idx);
   hipStream_t st = (hipStream_t)stream;
   const uint8_t* lb = (const uint8_t*)d_l_bases; const uint8_t* lq = (const uint8_t*)d_l_quals;
   const uint8_t* rb = (const uint8_t*)d_r_bases; const uint8_t* rq = (const uint8_t*)d_r_quals;
@@ -938,33 +937,13 @@ int gf_fast_merge_find_device(const gf_index* idx, const void* d_l_bases, const 
     GF_HIP(hipGetLastError());
     return GF_OK;
   }
-  // packed streams of both buffers: n * lmax bases each from the first read on; pairs that lie
-  // beyond them (gaps, reads longer than max_read_len) take the byte loop inside the kernel
-  const int lmax = std::max(max_read_len, 32);
-  const uint64_t cap_chunks = ((uint64_t)n * (uint64_t)lmax + 15) / 16 + 8;
-  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t sz_pkg = al((cap_chunks + 64) * sizeof(uint32_t));
-  const size_t sz_ivg = al((cap_chunks / 2 + 64) * sizeof(uint32_t));
-  std::lock_guard<std::mutex> ws_lock(mix->ws_mu);  // held until this call's launches are queued
-  void* base = nullptr;
-  int rc = acquire_workspace(mix, st, 2 * (sz_pkg + sz_ivg), &base);
-  if (rc != GF_OK) return rc;
-  uint8_t* wp = (uint8_t*)base;
-  uint32_t* pkg1 = (uint32_t*)wp; wp += sz_pkg;
-  uint32_t* ivg1 = (uint32_t*)wp; wp += sz_ivg;
-  uint32_t* pkg2 = (uint32_t*)wp; wp += sz_pkg;
-  uint32_t* ivg2 = (uint32_t*)wp;
-  GfStream S1, S2;
-  S1.pkg = pkg1; S1.ivg = ivg1; S1.cap_bases = cap_chunks * 16;
-  S2.pkg = pkg2; S2.ivg = ivg2; S2.cap_bases = cap_chunks * 16;
-  const int g_pack = (int)std::min<uint64_t>((cap_chunks + 255) / 256, (uint64_t)idx->n_cus * 64);
-  hipLaunchKernelGGL(gf_k_pack, dim3(g_pack), dim3(256), 0, st, lb, lo, n, cap_chunks, pkg1, (uint16_t*)ivg1);
-  hipLaunchKernelGGL(gf_k_pack_rc, dim3(g_pack), dim3(256), 0, st, rb, ro, n, cap_chunks, pkg2, (uint16_t*)ivg2);
+  // groups of 64 pairs per wavefront, each packing its own spans into LDS
+  const int g2 = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 16);
   if (max_read_len <= 160)
-    hipLaunchKernelGGL((gf_k_merge_find<10>), dim3(grid), dim3(256), 0, st, S1, S2, lb, lq, lo, rb, rq, ro, n,
+    hipLaunchKernelGGL((gf_k_merge_find_stream<10>), dim3(g2), dim3(256), 0, st, lb, lq, lo, rb, rq, ro, n,
                        (int32_t*)d_out_len, (int32_t*)d_out_diff);
   else
-    hipLaunchKernelGGL((gf_k_merge_find<16>), dim3(grid), dim3(256), 0, st, S1, S2, lb, lq, lo, rb, rq, ro, n,
+    hipLaunchKernelGGL((gf_k_merge_find_stream<16>), dim3(g2), dim3(256), 0, st, lb, lq, lo, rb, rq, ro, n,
                        (int32_t*)d_out_len, (int32_t*)d_out_diff);
   GF_HIP(hipGetLastError());
   return GF_OK;
