@@ -326,9 +326,55 @@ __global__ __launch_bounds__(256) void gf_k_merge_find_bytes(const uint8_t* __re
 }
 
 // ---- K_merge_write: block per 256 pairs; each thread fetches its pair's layout, the merged
-// pairs are listed in LDS and each is written by one wavefront, 64 bytes per step
+// pairs are listed in LDS and written by the wavefronts, two pairs at a time per wavefront
+// and 320 bytes of each in flight: a merged pair is one load round trip, and the kernel's
+// time is the number of such round trips a wavefront makes one after the other
 // (read.rs:379-428).  in_len[p] = merged length from the find kernel (0 = not merged),
 // out_pos[p] = where it goes. ----
+struct GfMergeBytes {
+  uint8_t a1[5], b1[5], a2[5], b2[5];  // R1 base/quality, R2 base/quality for output bytes lane, lane+64, ..
+};
+
+__device__ __forceinline__ void gf_mw_load(GfMergeBytes& g, const uint8_t* __restrict__ s1, const uint8_t* __restrict__ q1,
+                                           const uint8_t* __restrict__ s2, const uint8_t* __restrict__ q2, int len1,
+                                           int len2, int mlen, int offset, int k0, int lane) {
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int k = k0 + 64 * u + lane;
+    g.a1[u] = g.b1[u] = g.a2[u] = g.b2[u] = 0;
+    if (k < mlen) {
+      if (k < len1) { g.a1[u] = s1[k]; g.b1[u] = q1[k]; }
+      if (k >= offset) { g.a2[u] = s2[len2 - 1 - (k - offset)]; g.b2[u] = q2[len2 - 1 - (k - offset)]; }
+    }
+  }
+}
+
+__device__ __forceinline__ void gf_mw_store(const GfMergeBytes& g, uint8_t* __restrict__ os, uint8_t* __restrict__ oq,
+                                            int len1, int mlen, int offset, int k0, int lane) {
+  const int olen = len1 - offset;
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int k = k0 + 64 * u + lane;
+    if (k < mlen) {
+      uint8_t cs = g.a1[u], cq = g.b1[u];
+      if (k >= offset) {
+        cs = gf_complement(g.a2[u]);
+        cq = g.b2[u];
+        if (k - offset < olen) {
+          if (g.a1[u] != cs) {
+            if (g.b1[u] >= '?' && cq <= '0') { cs = g.a1[u]; cq = g.b1[u]; }
+          } else {
+            const uint32_t q = (uint32_t)g.b1[u] + (uint32_t)cq - 33u;  // add the pair's qualities, cap at 'Z'
+            cq = q >= (uint32_t)'Z' ? (uint8_t)'Z' : (uint8_t)q;
+          }
+        }
+      }
+      os[k] = cs;
+      oq[k] = cq;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restrict__ l_bases,
                                                         const uint8_t* __restrict__ l_quals,
                                                         const int64_t* __restrict__ l_off,
@@ -362,47 +408,23 @@ __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restric
     }
     __syncthreads();
     const unsigned int cnt = s_cnt;
-    for (unsigned int e = wave; e < cnt; e += 4) {
-      const int len1 = s_len1[e], len2 = s_len2[e], mlen = s_mlen[e];
-      const int offset = mlen - len2, olen = len1 - offset;
-      const uint8_t* s1 = l_bases + s_l[e];
-      const uint8_t* q1 = l_quals + s_l[e];
-      const uint8_t* s2 = r_bases + s_r[e];
-      const uint8_t* q2 = r_quals + s_r[e];
-      uint8_t* os = out_bases + s_dst[e];
-      uint8_t* oq = out_quals + s_dst[e];
-      for (int k0 = 0; k0 < mlen; k0 += 256) {  // four 64-byte steps in flight
-        uint8_t a1[4], b1[4], a2[4], b2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = k0 + 64 * u + lane;
-          a1[u] = b1[u] = a2[u] = b2[u] = 0;
-          if (k < mlen) {
-            if (k < len1) { a1[u] = s1[k]; b1[u] = q1[k]; }
-            if (k >= offset) { a2[u] = s2[len2 - 1 - (k - offset)]; b2[u] = q2[len2 - 1 - (k - offset)]; }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = k0 + 64 * u + lane;
-          if (k < mlen) {
-            uint8_t cs = a1[u], cq = b1[u];
-            if (k >= offset) {
-              cs = gf_complement(a2[u]);
-              cq = b2[u];
-              if (k - offset < olen) {
-                if (a1[u] != cs) {
-                  if (b1[u] >= '?' && cq <= '0') { cs = a1[u]; cq = b1[u]; }
-                } else {
-                  const uint32_t q = (uint32_t)b1[u] + (uint32_t)cq - 33u;  // add the pair's qualities, cap at 'Z'
-                  cq = q >= (uint32_t)'Z' ? (uint8_t)'Z' : (uint8_t)q;
-                }
-              }
-            }
-            os[k] = cs;
-            oq[k] = cq;
-          }
-        }
+    for (unsigned int e0 = 2 * wave; e0 < cnt; e0 += 8) {
+      const unsigned int e1 = e0 + 1;
+      const bool two = e1 < cnt;
+      const unsigned int ex = two ? e1 : e0;
+      const int len1a = s_len1[e0], len2a = s_len2[e0], mla = s_mlen[e0];
+      const int len1b = s_len1[ex], len2b = s_len2[ex], mlb = two ? s_mlen[ex] : 0;
+      const int offa = mla - len2a, offb = mlb - len2b;
+      const int mmax = mla > mlb ? mla : mlb;
+      for (int k0 = 0; k0 < mmax; k0 += 320) {
+        GfMergeBytes ga, gb;
+        gf_mw_load(ga, l_bases + s_l[e0], l_quals + s_l[e0], r_bases + s_r[e0], r_quals + s_r[e0], len1a, len2a, mla,
+                   offa, k0, lane);
+        gf_mw_load(gb, l_bases + s_l[ex], l_quals + s_l[ex], r_bases + s_r[ex], r_quals + s_r[ex], len1b, len2b, mlb,
+                   offb, k0, lane);
+        __builtin_amdgcn_sched_barrier(0);  // both pairs' loads before anybody's stores
+        gf_mw_store(ga, out_bases + s_dst[e0], out_quals + s_dst[e0], len1a, mla, offa, k0, lane);
+        gf_mw_store(gb, out_bases + s_dst[ex], out_quals + s_dst[ex], len1b, mlb, offb, k0, lane);
       }
     }
   }
