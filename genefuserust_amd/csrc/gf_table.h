@@ -88,13 +88,13 @@ struct GfTable {
 // from its high bits (mulhi), the two bit positions from its low bits folded with the
 // middle ones.  (A full murmur finaliser here cost four 32-bit multiplies per look-up,
 // quarter-rate instructions, in a kernel that does 34 look-ups per read.)
-#ifdef GF_BLOOM_OLDHASH
-#define GF_BLOOM_HASH(x) (gf_mix32(x) * 0x9E3779B1u)
-#define GF_BLOOM_BITS(h) ((1u << ((h) & 31u)) | (1u << (((h) >> 5) & 31u)))
-#else
-#define GF_BLOOM_HASH(x) ((uint32_t)(x) * 0x9E3779B1u)
+// Both strands of every gene are indexed, so nearly every 14-mer in the table is there with
+// its reverse complement: the filter stores the smaller of the two (and looks up the smaller
+// of the two), which halves the items it has to hold — at 3 MiB that is 6 bits per item
+// instead of 3, a false-positive rate of ~8 % instead of ~22 %.  No symmetry is *assumed*:
+// every key's two 14-mers are inserted in canonical form, whatever else the table holds.
+#define GF_BLOOM_HASH(x) ((uint32_t)gf_canon14(x) * 0x9E3779B1u)
 #define GF_BLOOM_BITS(h) ((1u << (((h) ^ ((h) >> 15)) & 31u)) | (1u << ((((h) ^ ((h) >> 15)) >> 5) & 31u)))
-#endif
 #define GF_BLOOM_WORD(h, nwords) ((uint32_t)(((uint64_t)(h) * (uint64_t)(nwords)) >> 32))
 
 #if defined(__HIPCC__)
@@ -127,6 +127,23 @@ GF_HD uint32_t gf_field_reverse(uint32_t x) {
 
 // key of the reverse-complement window (complement = code ^ 2 under A0 C1 T2 G3)
 GF_HD uint32_t gf_revcomp_key(uint32_t key) { return gf_field_reverse(key) ^ 0xAAAAAAAAu; }
+
+// canonical form of a 14-mer (28 bits, base 0 in the low bits): the smaller of it and its
+// reverse complement
+GF_HD uint32_t gf_canon14(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r = __brev(x);  // fields reversed, and the two bits of each field swapped
+  r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+#else
+  uint32_t r = gf_field_reverse(x);
+#endif
+  r = (r >> 4) ^ 0x0AAAAAAAu;
+#ifdef GF_BLOOM_NOCANON
+  return x;
+#else
+  return r < x ? r : x;
+#endif
+}
 
 // reference-coded k-mer (indexer.rs:789-913) -> device key
 GF_HD uint32_t gf_key_from_ref_kmer(uint32_t k) {
