@@ -784,7 +784,11 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           if ((nvalid ^ key[0] ^ key[1] ^ key[2] ^ key[3] ^ cwb[0] ^ cwb[1] ^ cwb[2] ^ cwb[NT - 1] ^ okm) == 0x1234567u) counts[r] = 1;
           okm = 0;
 #endif
-          // all four seeds go through the presence filter together (L2 hits)
+          // all four seeds go through the presence filter together (L2 hits).  The 14-mer asked
+          // about (bases 32s+2 .. 32s+15) is the last 14 bases of window 16s and the first 14 of
+          // window 16s+1: a clear bit pair proves that neither can vote, which spares the filter
+          // pass those windows.
+          uint32_t kill[2] = {0, 0};  // windows 0..63 proven unable to vote (seeds sit at windows 0, 16, 32, 48)
           if (T.bloom_in_l2) {
             uint32_t fw[4], fb[4];
 #pragma unroll
@@ -795,7 +799,10 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-              if ((fw[s] & fb[s]) != fb[s]) okm &= ~(1u << s);
+              if (2 * s < PW && (fw[s] & fb[s]) != fb[s]) {
+                okm &= ~(1u << s);
+                kill[s >> 1] |= 3u << (16 * (s & 1));
+              }
           }
 #if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 3
           if (okm == 0x1234567u) counts[r] = 1;
@@ -809,8 +816,14 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             okm &= okm - 1;
             const uint32_t ks = s == 0 ? key[0] : (s == 1 ? key[1] : (s == 2 ? key[2] : key[3]));
             const uint32_t val = gf_lookup(T, ks);
-            if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
+            const uint32_t ty = val >> GF_TYPE_SHIFT;
+            if (ty == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
+            else if (ty != GF_TYPE_DUPES) kill[s >> 1] |= 1u << (16 * (s & 1));  // absent or >= 6 sites: no vote
           }
+          // windows that cannot vote are not "clean" for what follows
+          nvalid -= __popc(cwb[0] & kill[0]) + __popc(cwb[1] & kill[1]);
+          cwb[0] &= ~kill[0];
+          cwb[1] &= ~kill[1];
 #if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 4
           if (K == 0x1234567u) counts[r] = 1;
           K = GF_NONE_LIN;
