@@ -532,6 +532,8 @@ __global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const u
 // One undecided read: w[0] = read index in the batch, w[1] = v1 | v2 << 8, w[2 .. 2+NT) = one
 // bit per stride-2 window still to be asked (bit b of word k = window 32k + b), then the
 // read's PW words of 2-bit codes; padded to whole 16-byte vectors.
+#define GF_ENTRY_FILTERED 0x80000000u  // in w[1]: the windows listed have already passed the presence filter
+
 template <int PW>
 struct GfPipeEntryW {  // 64 B (PW = 10), 96 B (PW = 16), 112 B (PW = 20)
   static constexpr int NT = PW <= 16 ? 4 : (PW + 3) / 4;  // 8 windows per word of the read
@@ -828,6 +830,52 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           if (K == 0x1234567u) counts[r] = 1;
           K = GF_NONE_LIN;
 #endif
+          // A read without a candidate diagonal (background, mostly) goes through the presence
+          // filter right here: seed+verify is bound by L2-missing requests and leaves the L2's hit
+          // bandwidth idle, which is exactly what the filter pass is short of.  Windows 8j .. 8j+7
+          // per step, two windows per look-up; stops when even the windows not asked yet cannot
+          // reach the gate.  Survivors carry the windows still standing and a flag that tells
+          // gf_k_probe_filter to pass them on as they are.
+          bool filt_done = false, filt_dead = false;
+          uint32_t pp[NT];
+#pragma unroll
+          for (int k = 0; k < NT; ++k) pp[k] = 0;
+#ifndef GF_SV_NO_INLINE_FILTER
+          if (K == GF_NONE_LIN && T.bloom_in_l2) {
+            filt_done = true;
+            int npos = 0, rem = nvalid;
+            uint32_t wlo = gf_cut_pk(s_pk, w0, sh, 0);
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+              const uint32_t whi = j + 1 < PW ? gf_cut_pk(s_pk, w0, sh, j + 1) : 0u;
+              if (!filt_dead) {
+                const uint32_t byte = (cwb[j >> 2] >> (8 * (j & 3))) & 0xFFu;  // this word's 8 windows
+                uint32_t word[4], bits[4], both[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  both[u] = (byte >> (2 * u)) & 3u;
+                  // windows 8j+2u and 8j+2u+1 share the 14-mer at bases 16j + 4u+2 .. 16j + 4u+15
+                  const uint32_t s14 = __builtin_amdgcn_alignbit(whi, wlo, 8u * (uint32_t)u + 4u) & 0x0FFFFFFFu;
+                  const uint32_t h2 = GF_BLOOM_HASH((s14));
+                  bits[u] = GF_BLOOM_BITS(h2);
+                  word[u] = 0;
+                  if (both[u]) word[u] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const int cnt = (int)(both[u] & 1u) + (int)(both[u] >> 1);
+                  rem -= cnt;
+                  if (both[u] && (word[u] & bits[u]) == bits[u]) {
+                    pp[j >> 2] |= both[u] << (8 * (j & 3) + 2 * u);
+                    npos += cnt;
+                  }
+                }
+                filt_dead = npos + rem < GF_MAJOR_KEYS / 2;
+              }
+              wlo = whi;
+            }
+          }
+#endif
           // pass B: verify the candidate diagonal against the genes in site-code space, a
           // word of the read at a time: window w counts iff its 16 bases equal the bases of
           // site K + 2w and that site is the only site of its key
@@ -870,8 +918,13 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           }
           // every other diagonal gets at most one vote per window that can still vote
           const int open = nvalid - v1;
-          if (v1 + open < GF_MAJOR_KEYS / 2 || open < GF_MINOR_KEYS / 2) {
+          if (v1 + open < GF_MAJOR_KEYS / 2 || open < GF_MINOR_KEYS / 2 || filt_dead) {
             counts[r] = 0;
+          } else if (filt_done) {
+            undecided = true;
+            e_v1v2 = GF_ENTRY_FILTERED;  // v1 = v2 = 0; the windows below have been through the filter
+#pragma unroll
+            for (int k = 0; k < NT; ++k) e_todo[k] = pp[k];
           } else {
             undecided = true;
             e_v1v2 = (uint32_t)v1;  // v2 = 0: one candidate diagonal per read
@@ -934,12 +987,17 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
     for (int k = 0; k < NT; ++k) m[k] = pp[k] = 0;
     if (t < nb) {
       gf_entry_load<PW>(my_list + t, r, v1v2, m, pk);
+      const bool filtered = (v1v2 & GF_ENTRY_FILTERED) != 0;  // seed+verify has asked the filter already
+      v1v2 &= ~GF_ENTRY_FILTERED;
       const int v1 = (int)(v1v2 & 0xFFu), v2 = (int)((v1v2 >> 8) & 0xFFu);
       int npos = 0, rem = 0;  // not ruled out / not asked yet
 #pragma unroll
       for (int k = 0; k < NT; ++k) rem += __popc(m[k]);
       bool dead = false;
-      if (T.bloom_words) {
+      if (filtered) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) pp[k] = m[k];
+      } else if (T.bloom_words) {
         // windows 2q and 2q+1 share the 14-mer at bases 4q+2 .. 4q+15: one lookup for both.
         // Fully unrolled over the pairs (compile-time shifts on the words in registers),
         // four look-ups in flight per step.
