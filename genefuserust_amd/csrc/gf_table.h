@@ -138,11 +138,7 @@ GF_HD uint32_t gf_canon14(uint32_t x) {
   uint32_t r = gf_field_reverse(x);
 #endif
   r = (r >> 4) ^ 0x0AAAAAAAu;
-#ifdef GF_BLOOM_NOCANON
-  return x;
-#else
   return r < x ? r : x;
-#endif
 }
 
 // reference-coded k-mer (indexer.rs:789-913) -> device key
