@@ -1147,17 +1147,7 @@ __global__ __launch_bounds__(WAVES * 64, LCAP <= 256 ? 8 : (LCAP <= 1024 ? 3 : 1
     gf_wave_lds_sync();
     const uint32_t sh = gf_stage_read<LCAP>(S, bases + off0, L, lane);
     gf_wave_lds_sync();
-    int nvotes;
-#ifdef GF_LIST_SEEDVERIFY
-    if constexpr (LCAP <= 256) nvotes = gf_first_pass_seed_verify<LCAP>(T, S, L, sh, lane);
-    else nvotes = gf_first_pass_probe_all<LCAP>(T, S, L, sh, lane);
-    if (nvotes < 0) {
-      if (lane == 0) counts[r] = 0;
-      continue;
-    }
-#else
-    nvotes = gf_first_pass_probe_all<LCAP>(T, S, L, sh, lane);
-#endif
+    const int nvotes = gf_first_pass_probe_all<LCAP>(T, S, L, sh, lane);
     gf_finish_read<LCAP>(T, S, L, sh, nvotes, lane, r, counts, matches);
   }
 }
