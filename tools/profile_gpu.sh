@@ -20,5 +20,5 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
 done
 cd $REPO
 python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
-find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv ; 2>/dev/null
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \; 2>/dev/null
 cat $OUT/summary.txt
