@@ -121,6 +121,19 @@ def main() -> None:
     read_id_base = rank * n
     stream = torch.cuda.current_stream(dev)
 
+    # N > 1: the per-rank hit lists are merged by one asynchronous all-gather per step
+    # (genefuserust_amd/dist.py::HitExchange): fixed-capacity blocks, no host round trip, so the
+    # exchange of step k overlaps the mapping of step k+1; every step's merged list is finished
+    # (waited for and packed on the device) inside the timed region.
+    exch = None
+    if world > 1:
+        if rehearsal or os.environ.get("GF_BENCH_PLAIN_ALLGATHER") == "1":
+            exch = None  # gloo on host copies (or asked for): the plain allgather_hits path
+        else:
+            from genefuserust_amd.dist import HitExchange
+            exch = HitExchange(cap=max(4096, n // 512), device=dev)
+    pending = []
+
     def step(ev=None):
         if ev is not None:
             ev[0].record(stream)
@@ -129,17 +142,31 @@ def main() -> None:
             ev[1].record(stream)
         hits, n_hits = ix.compact_hits_device(counts, matches, n, read_id_base=read_id_base, cap=n // 16)
         if world > 1:
-            return allgather_hits(hits, n_hits)
+            if exch is None:
+                return allgather_hits(hits, n_hits)
+            pending.append(exch.start(hits, n_hits))
+            if len(pending) > 1:  # finish the previous step's exchange while this step's kernels run
+                return exch.finish(pending.pop(0))
+            return None
         return hits, n_hits
+
+    def drain():
+        out = None
+        while pending:
+            out = exch.finish(pending.pop(0))
+        return out
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     out = None
     for k in range(args.steps):
         out = step(evs[k])
+    last = drain()
+    out = last if last is not None else out
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -166,7 +193,13 @@ def main() -> None:
 
     total_reads = n * world * args.steps
     value = total_reads / elapsed
-    n_hits_total = int(out.shape[0]) if world > 1 else int(out[1].item())
+    if world == 1:
+        n_hits_total = int(out[1].item())
+    elif isinstance(out, tuple):  # HitExchange: (merged, total, overflow)
+        assert not bool(out[2].item()), "hit exchange capacity exceeded: raise HitExchange cap"
+        n_hits_total = int(out[1].item())
+    else:
+        n_hits_total = int(out.shape[0])
 
     result = {
         "metric": "150bp_reads_per_s_map_read_vs_druggable_shaped_index",

@@ -58,3 +58,56 @@ def allgather_hits(hits: torch.Tensor, n_hits: torch.Tensor, group=None) -> torc
     dist.all_gather_into_tensor(recv.view(world * mx, HIT_WORDS), send, group=group)
     parts = [recv[r, : int(counts_h[r])] for r in range(world)]
     return torch.cat(parts, dim=0)
+
+
+class HitExchange:
+    """The same merge without a host round trip, so that it overlaps the next batch.
+
+    ``allgather_hits`` reads the per-rank counts on the host before it can size the second
+    collective — one synchronisation per batch, which at ~3 ms of kernels per 20 M reads costs
+    a tenth of the step.  Here every rank sends a fixed-capacity block (row 0 = its count, then
+    up to ``cap`` records) in ONE asynchronous all-gather; the valid prefixes are packed into
+    rank order on the device.  ``start`` enqueues, ``finish`` waits for that batch only; two
+    buffer sets, so batch k+1 can be started while batch k is still in flight.  A rank whose
+    count exceeds ``cap`` is reported through ``overflow`` (the caller falls back to
+    ``allgather_hits`` for that batch).
+    """
+
+    def __init__(self, cap: int, device, group=None, depth: int = 2):
+        self.cap, self.group = int(cap), group
+        self.world = dist.get_world_size(group)
+        self.send = [torch.zeros((self.cap + 1, HIT_WORDS), dtype=torch.int64, device=device) for _ in range(depth)]
+        self.recv = [torch.zeros((self.world, self.cap + 1, HIT_WORDS), dtype=torch.int64, device=device)
+                     for _ in range(depth)]
+        self.slot = 0
+        self._iota = torch.arange(self.cap, device=device, dtype=torch.int64)
+
+    def start(self, hits: torch.Tensor, n_hits: torch.Tensor):
+        """hits int64[>=?, 6] ordered records of this rank, n_hits int64[1].  Returns a handle."""
+        k = self.slot
+        self.slot = (self.slot + 1) % len(self.send)
+        send, recv = self.send[k], self.recv[k]
+        rows = min(self.cap, hits.shape[0])
+        send[0, 0] = n_hits[0]
+        send[1:1 + rows] = hits[:rows]
+        work = dist.all_gather_into_tensor(recv.view(self.world * (self.cap + 1), HIT_WORDS), send, group=self.group,
+                                           async_op=True)
+        return work, k
+
+    def finish(self, handle):
+        """(merged int64[world*cap + 1, 6], total int64[1], overflow bool[1]) on the device; rows
+        [0, total) of ``merged`` are the global ordered hit list, the rest is scratch."""
+        work, k = handle
+        work.wait()
+        recv = self.recv[k]
+        counts = recv[:, 0, 0]
+        overflow = (counts > self.cap).any().reshape(1)
+        c = counts.clamp(max=self.cap)
+        starts = torch.cumsum(c, 0) - c
+        total = c.sum().reshape(1)
+        trash = self.world * self.cap
+        idx = starts[:, None] + self._iota[None, :]
+        idx = torch.where(self._iota[None, :] < c[:, None], idx, torch.full_like(idx, trash))
+        merged = torch.empty((trash + 1, HIT_WORDS), dtype=torch.int64, device=recv.device)
+        merged.index_copy_(0, idx.reshape(-1), recv[:, 1:, :].reshape(-1, HIT_WORDS))
+        return merged, total, overflow

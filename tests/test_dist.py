@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from genefuserust_amd.dist import HIT_WORDS, allgather_hits, shard_range
+from genefuserust_amd.dist import HIT_WORDS, HitExchange, allgather_hits, shard_range
 
 
 def _free_port():
@@ -48,6 +48,17 @@ def _worker(rank, world, port, n, q):
         h2, c2 = (hits, n_hits) if rank == 1 else (empty, torch.zeros(1, dtype=torch.int64))
         q.put((rank, allgather_hits(h2, c2).numpy().copy()))
         q.put((rank, allgather_hits(empty, torch.zeros(1, dtype=torch.int64)).numpy().copy()))
+        # the sync-free exchange: two batches in flight, then finished in order
+        ex = HitExchange(cap=n // world + 8, device="cpu")   # the same capacity on every rank
+        ha = ex.start(hits, n_hits)
+        hb = ex.start(h2, c2)
+        for h in (ha, hb):
+            merged, total, overflow = ex.finish(h)
+            assert not bool(overflow)
+            q.put((rank, merged[: int(total)].numpy().copy()))
+        small = HitExchange(cap=3, device="cpu")   # too small for this rank's list: reported, not silently cut
+        _, _, overflow = small.finish(small.start(hits, n_hits))
+        assert bool(overflow)
     finally:
         dist.destroy_process_group()
 
@@ -72,7 +83,7 @@ def test_allgather_hits_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(3 * world)]
+    got = [q.get(timeout=120) for _ in range(5 * world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -82,8 +93,34 @@ def test_allgather_hits_gloo(world):
     lo1, hi1 = shard_range(n, 1, world)
     w2, c2 = _fake_hits(lo1, hi1, cap=hi1 - lo1 + 1)
     for r in range(world):
-        first, second, third = by_rank[r]
+        first, second, third, ex_first, ex_second = by_rank[r]
+        assert np.array_equal(ex_first, want) and np.array_equal(ex_second, w2[: int(c2)].numpy())
         assert np.array_equal(first, want)            # same list as one process, ascending read id
         assert (np.diff(first[:, 0]) > 0).all()
         assert np.array_equal(second, w2[: int(c2)].numpy())
         assert third.shape == (0, HIT_WORDS)
+
+
+@pytest.mark.gpu
+def test_hit_exchange_on_the_device(gpu_device):
+    """The sync-free exchange over RCCL (backend "nccl"), one rank: the CUDA path of the
+    packing and of the device-side merge (more ranks need more GPUs than a test box has)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda", gpu_device)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        hits, n_hits = _fake_hits(0, 5000, cap=6000)
+        ex = HitExchange(cap=2048, device=dev)
+        h1 = ex.start(hits.to(dev), n_hits.to(dev))
+        h2 = ex.start(hits[:10].to(dev), torch.tensor([7], device=dev))
+        merged, total, overflow = ex.finish(h1)
+        assert not bool(overflow) and int(total) == int(n_hits)
+        assert torch.equal(merged[: int(total)].cpu(), hits[: int(n_hits)])
+        merged, total, overflow = ex.finish(h2)
+        assert int(total) == 7 and torch.equal(merged[:7].cpu(), hits[:7])
+        small = HitExchange(cap=100, device=dev)
+        _, _, overflow = small.finish(small.start(hits.to(dev), n_hits.to(dev)))
+        assert bool(overflow)
+    finally:
+        dist.destroy_process_group()
