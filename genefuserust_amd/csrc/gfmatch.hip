@@ -359,20 +359,28 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
                        ix->d_gdu);
     GF_HIP(hipGetLastError());
   }
-  // presence filter over 14-mers.  Small indexes: <= GF_BLOOM_KIB (default 3 MiB) so that it
-  // lives in every XCD's L2, as long as that leaves >= 2 bits per key.  Larger indexes: about
-  // GF_BLOOM_BIG_BPK (default 4) bits per key, resident in the Infinity Cache instead — a
-  // lookup is then an L2-missing request like a bucket probe, but one lookup answers for two
-  // windows and a negative answer spares both bucket probes.
+  // presence filter over canonical 14-mers.  Indexes up to ~14 M keys: <= GF_BLOOM_KIB (default
+  // 3 MiB) so that it lives in every XCD's L2.  Up to ~38 M keys: 1.75 bits per key, up to
+  // GF_BLOOM_MID_KIB (default 8 MiB) — no longer L2-resident, but still mostly L2 hits, and
+  // measured faster than the next form (IDX-C, 29 M keys: 4.04 vs 3.71 G reads/s; at 10 MiB and
+  // beyond the inline filter pass of seed+verify starts to lose).  Larger indexes: about
+  // GF_BLOOM_BIG_BPK (default 4) bits per key, resident in the Infinity Cache and used by the
+  // filter kernel only — a lookup is then an L2-missing request like a bucket probe, but one
+  // lookup answers for two windows and a negative answer spares both bucket probes.
   uint32_t bloom_words = 0, bloom_in_l2 = 0;
   {
-    size_t kib = 3072, big_bpk = 4;
+    size_t kib = 3072, mid_kib = 8192, big_bpk = 4;
     if (const char* e = getenv("GF_BLOOM_KIB")) kib = (size_t)atol(e);
+    if (const char* e = getenv("GF_BLOOM_MID_KIB")) mid_kib = (size_t)atol(e);
     if (const char* e = getenv("GF_BLOOM_BIG_BPK")) big_bpk = (size_t)atol(e);
     const uint64_t keys = stats[1];
-    const uint64_t cap_words = (uint64_t)kib * 1024 / 4;
+    const uint64_t cap_words = (uint64_t)kib * 1024 / 4, mid_words = (uint64_t)mid_kib * 1024 / 4;
+    const uint64_t want_words = keys * 7 / 128;  // 1.75 bits per key
     uint64_t words = std::min(std::max<uint64_t>(1024, keys / 2), cap_words);  // up to 16 bits per key
-    if (kib > 0 && words * 32 >= keys * 2) {
+    if (kib > 0 && want_words <= cap_words) {
+      bloom_in_l2 = 1;
+    } else if (kib > 0 && want_words <= mid_words) {
+      words = want_words;
       bloom_in_l2 = 1;
     } else if (kib > 0 && big_bpk > 0) {
       words = std::min<uint64_t>(keys * big_bpk / 32 + 1024, (64ull << 20) / 4);

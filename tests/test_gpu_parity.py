@@ -220,7 +220,7 @@ def test_with_loaded_ref_constructor(gpu_device, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, "0-nofilter", "0-bigfilter"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, "0-nofilter", "0-midfilter", "0-bigfilter"])
 @pytest.mark.parametrize("shape,scale,n_reads", [("IDX-T", 0.02, 60000), ("IDX-C", 0.004, 60000)])
 def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, variant, monkeypatch):
     """Repeat-rich synthetic genes (2 % repeat family, N bases) and a junction-heavy
@@ -231,8 +231,12 @@ def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, vari
     if variant == "0-nofilter":
         monkeypatch.setenv("GF_BLOOM_KIB", "0")
         variant = 0
-    elif variant == "0-bigfilter":  # what indexes too large for an L2-resident filter get
+    elif variant == "0-midfilter":  # indexes whose filter outgrows the L2 but is still used inline
         monkeypatch.setenv("GF_BLOOM_KIB", "1")
+        variant = 0
+    elif variant == "0-bigfilter":  # larger still: Infinity-Cache filter, used by the filter kernel only
+        monkeypatch.setenv("GF_BLOOM_KIB", "1")
+        monkeypatch.setenv("GF_BLOOM_MID_KIB", "1")
         variant = 0
     ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
     ix.make_index()
