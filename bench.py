@@ -215,9 +215,13 @@ def main() -> None:
         "dtype": "u32",
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL on one GPU over gloo: not a measurement)",
         "config": {
-            "workload": "BASELINE configs[1]: %d synthetic %d-bp read pairs (%d reads) per GPU vs %s "
-                        "(druggable.hg38-shaped: first 32 gene spans of testdata/cancer.csv, %d bp), mix %s"
-                        % (args.pairs, L, n, args.shape, info["total_bp"], args.mix),
+            "workload": "%s: %d synthetic %d-bp read pairs (%d reads) per GPU vs %s (%s, %d bp), mix %s"
+                        % ({"IDX-D": "BASELINE configs[1]", "IDX-C": "BASELINE configs[2] shape",
+                            "IDX-T": "BASELINE configs[0] gene set"}[args.shape], args.pairs, L, n, args.shape,
+                           {"IDX-D": "druggable.hg38-shaped: first 32 gene spans of testdata/cancer.csv",
+                            "IDX-C": "cancer.hg38-shaped: all 136 gene spans of testdata/cancer.csv",
+                            "IDX-T": "the 4 gene spans of testdata/fusions.csv"}[args.shape],
+                           info["total_bp"], args.mix),
             "reads_per_gpu_per_step": n,
             "read_len": L,
             "index_shape": args.shape,
