@@ -274,3 +274,44 @@ def test_scan_pair_end_policy(gpu_device, oracle):
                                                     (rm["right_contig"], rm["right_position"]))
     assert n_merged >= 30 and n_match >= 20
     ix.close()
+
+
+@pytest.mark.gpu
+def test_fast_merge_full_size_fragments(gpu_device):
+    """BASELINE-size property, no oracle: 4 M error-free pairs cut from random fragments of
+    150..330 bases.  Fragments of up to 270 bases overlap by >= 30 and must come back exactly
+    (bases = the fragment, qualities 'F' outside the overlap and 'Z' inside, diff 0); longer
+    fragments must not merge."""
+    import torch
+    from genefuserust_amd import Indexer
+    from genefuserust_amd.read_pair import fast_merge_device
+    n, L = 4_000_000, 150
+    dev = torch.device("cuda", gpu_device)
+    ix = Indexer.from_gene_slices([b"ACGT" * 64])
+    ix.make_index()
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    flen = torch.randint(150, 331, (n,), generator=g, device=dev)
+    frag = acgt[torch.randint(0, 4, (n, 330), generator=g, device=dev)]
+    ar = torch.arange(L, device=dev)
+    r1 = frag[:, :L].contiguous()
+    r2 = comp[torch.gather(frag, 1, flen[:, None] - 1 - ar[None, :]).long()]
+    q = torch.full((n * L,), ord("F"), dtype=torch.uint8, device=dev)
+    off = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    bases, quals, moff, diff = fast_merge_device(ix, r1.reshape(-1), q, off, r2.reshape(-1), q, off, L)
+    merges = flen <= 2 * L - 30
+    want_len = torch.where(merges, flen, torch.zeros_like(flen))
+    assert torch.equal(moff[1:] - moff[:-1], want_len)
+    assert int(diff.abs().sum()) == 0
+    cols = torch.arange(330, device=dev)[None, :]
+    keep = (cols < flen[:, None]) & merges[:, None]
+    assert torch.equal(bases, frag[keep])
+    olen = 2 * L - flen
+    in_overlap = (cols >= (L - olen)[:, None]) & (cols < L)
+    want_q = torch.where(in_overlap, torch.full_like(frag, ord("Z")), torch.full_like(frag, ord("F")))
+    assert torch.equal(quals, want_q[keep])
+    ix.close()

@@ -161,3 +161,28 @@ def test_files_to_matches(small_index, oracle, tmp_path):
         n_merged += m is not None
         n_hit += exp > 0
     assert n_merged > 200 and n_hit > 50
+
+
+@pytest.mark.gpu
+def test_fastq_cut_full_size_round_trip(small_index):
+    """BASELINE-size property: 5 M fixed-length records (1.6 GB of text) written on the device,
+    cut by the kernels, and compared with the tensors they were written from — every base and
+    every quality, no oracle involved."""
+    import torch
+    from genefuserust_amd.fastq import fastq_cut_device
+    from tools.bench_frontend import make_text
+    n, L = 5_000_000, 150
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    acgt = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device=dev)
+    bases = acgt[torch.randint(0, 5, (n * L,), generator=g, device=dev)]
+    quals = (33 + torch.randint(0, 42, (n * L,), generator=g, device=dev)).to(torch.uint8)
+    text = make_text(bases, quals, n, L, 1, dev)
+    batch = fastq_cut_device(small_index, text)
+    assert batch.n_records == n and batch.n_bad_quality == 0
+    assert torch.equal(batch.offsets, torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev))
+    assert torch.equal(batch.bases, bases) and torch.equal(batch.quals, quals)
+    # without the final newline the last record still counts; without its last line it does not
+    assert fastq_cut_device(small_index, text[:-1]).n_records == n
+    assert fastq_cut_device(small_index, text[:-(L + 1)]).n_records == n - 1
