@@ -120,6 +120,10 @@ def lib() -> C.CDLL:
     L.gf_fusion_map_read.restype = C.c_int
     L.gf_index_fusion_map_read.argtypes = [vp, vp, C.c_char_p, i64, C.POINTER(GfSeqMatch), i32, C.POINTER(GfReadMatch)]
     L.gf_index_fusion_map_read.restype = C.c_int
+    L.gf_readmatch_filter.argtypes = [vp, C.c_char_p, i64, i32]
+    L.gf_readmatch_filter.restype = C.c_int
+    L.gf_readmatch_order.argtypes = [i32, i64, C.c_char_p, i64, i32, i64, C.c_char_p, i64]
+    L.gf_readmatch_order.restype = C.c_int
     L.gf_fastq_workspace_bytes.argtypes = [i64]
     L.gf_fastq_workspace_bytes.restype = i64
     L.gf_fastq_index_device.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp]

@@ -923,6 +923,38 @@ int gf_index_fusion_map_read(const gf_index* idx, const uint8_t* gene_reversed, 
   return gf_fusion_map_read(p.data(), l.data(), (int32_t)p.size(), gene_reversed, seq, len, mapping, n_mapping, out);
 }
 
+// ---- FusionMapper::filter_matches (minus remove_alignables) and the order of sort_matches ----
+static bool host_low_complexity(const char* s, int64_t n) {  // fusion_mapper.rs:559-569
+  if (n < 20) return true;
+  int diff = 0;  // dis_connected_count, utils/mod.rs:48-56
+  for (int64_t i = 0; i + 1 < n; ++i) diff += s[i] != s[i + 1];
+  return diff < 7;
+}
+
+int gf_readmatch_filter(const gf_readmatch* rm, const char* seq, int64_t len, int32_t deletion_threshold) {
+  if (!rm || len < 0 || (len > 0 && !seq)) return fail(GF_ERR_ARG, "bad argument");
+  const int64_t cut = (int64_t)rm->read_break + 1;
+  if (cut < 0 || cut > len) return fail(GF_ERR_ARG, "read_break outside the read");  // the reference's subchars panics
+  if (host_low_complexity(seq, cut) || host_low_complexity(seq + cut, len - cut)) return 1;
+  if (rm->left_distance + rm->right_distance >= 5) return 2;
+  if (rm->left_contig == rm->right_contig) {
+    int64_t d = (int64_t)rm->left_position - (int64_t)rm->right_position;
+    if (d < 0) d = -d;
+    if (d < (int64_t)deletion_threshold) return 3;
+  }
+  return 0;
+}
+
+int gf_readmatch_order(int32_t a_break, int64_t a_len, const char* a_name, int64_t a_name_len, int32_t b_break,
+                       int64_t b_len, const char* b_name, int64_t b_name_len) {
+  if (a_break != b_break) return a_break > b_break ? -1 : 1;  // read_break descending
+  if (a_len != b_len) return a_len < b_len ? -1 : 1;          // shorter read first
+  const int64_t n = a_name_len < b_name_len ? a_name_len : b_name_len;
+  int c = n > 0 ? memcmp(a_name, b_name, (size_t)n) : 0;
+  if (c == 0) c = a_name_len < b_name_len ? -1 : (a_name_len > b_name_len ? 1 : 0);
+  return c > 0 ? -1 : (c < 0 ? 1 : 0);  // name descending
+}
+
 // ---- SequenceReadPair::fast_merge on the device ----
 int gf_fast_merge_find_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
                               const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,

@@ -40,6 +40,7 @@ class ReadMatch:
     m_left_distance: int
     m_right_distance: int
     m_reversed: bool = False
+    m_name: bytes = b""   # SequenceRead.m_name: the last key of the sort order (read_match.rs:226)
 
 
 def edit_distance(a: BytesLike, b: BytesLike) -> int:
@@ -83,6 +84,38 @@ class FusionMapper:
                   for k in range(int(counts[r]))]
             out[int(r)] = self._tail(seqs[int(r)], mp)
         return out
+
+    @staticmethod
+    def _c_readmatch(m: ReadMatch) -> GfReadMatch:
+        return GfReadMatch(m.m_read_break, m.m_gap, m.m_left_distance, m.m_right_distance, m.m_left_gp.position,
+                           m.m_right_gp.position, m.m_left_gp.contig, m.m_right_gp.contig)
+
+    def filter_matches(self, matches: Sequence[ReadMatch], deletion_threshold: int = 50):
+        """FusionMapper::filter_matches without remove_alignables (fusion_mapper.rs:276-376):
+        (kept, {"complexity": n, "distance": n, "indels": n}), the reference's three counters."""
+        kept: List[ReadMatch] = []
+        removed = {"complexity": 0, "distance": 0, "indels": 0}
+        names = (None, "complexity", "distance", "indels")
+        for m in matches:
+            seq = _as_bytes(m.m_read)
+            rm = self._c_readmatch(m)
+            why = _lib.check(_lib.lib().gf_readmatch_filter(C.byref(rm), seq, len(seq), int(deletion_threshold)))
+            if why == 0:
+                kept.append(m)
+            else:
+                removed[names[why]] += 1
+        return kept, removed
+
+    @staticmethod
+    def sort_matches(matches: Sequence[ReadMatch]) -> List[ReadMatch]:
+        """fusion_mapper.rs:378-384: read_break descending, shorter read first, name descending."""
+        import functools
+        L = _lib.lib()
+
+        def cmp(a: ReadMatch, b: ReadMatch) -> int:
+            return L.gf_readmatch_order(a.m_read_break, len(a.m_read), a.m_name, len(a.m_name), b.m_read_break,
+                                        len(b.m_read), b.m_name, len(b.m_name))
+        return sorted(matches, key=functools.cmp_to_key(cmp))
 
     def scan_single_end(self, reads: Sequence[BytesLike]) -> List[Optional[ReadMatch]]:
         """sescanner.rs:188-195: map the read; when it is mapable but gives no match, map its

@@ -185,6 +185,18 @@ typedef struct gf_readmatch {
 int gf_fusion_map_read(const char* const* fusion_seqs, const int64_t* fusion_lens, int32_t n_genes,
                        const uint8_t* gene_reversed, const char* seq, int64_t len,
                        const gf_seqmatch* mapping, int32_t n_mapping, gf_readmatch* out);
+/* FusionMapper::filter_matches without remove_alignables (fusion_mapper.rs:276-376), for one
+ * match: 0 = kept, 1 = removed by remove_by_complexity (either side of the break shorter than
+ * 20 bases or with fewer than 7 changes of base, :298-320 and :559-569, utils/mod.rs:48-56),
+ * 2 = by remove_by_distance (left + right edit distance >= 5, :322-348), 3 = by
+ * remove_indels (same gene and |left - right position| < deletion_threshold, the reference's
+ * default is 50, :350-376) — the first of the three that applies, in the reference's order. */
+int gf_readmatch_filter(const gf_readmatch* rm, const char* seq, int64_t len, int32_t deletion_threshold);
+/* The order sort_matches gives (fusion_mapper.rs:378-384: sort_by(|a,b| b.partial_cmp(a)) over
+ * read_match.rs:203-228): read_break descending, then shorter read first, then name
+ * descending (bytes).  Returns < 0 when a comes before b, 0 when they tie, > 0 otherwise. */
+int gf_readmatch_order(int32_t a_break, int64_t a_len, const char* a_name, int64_t a_name_len, int32_t b_break,
+                       int64_t b_len, const char* b_name, int64_t b_name_len);
 /* the same with the fusion sequences of an index */
 int gf_index_fusion_map_read(const gf_index* idx, const uint8_t* gene_reversed, const char* seq, int64_t len,
                              const gf_seqmatch* mapping, int32_t n_mapping, gf_readmatch* out);

@@ -271,3 +271,30 @@ def fastq_records(text: bytes):
     if lines and lines[-1] == b"":
         lines.pop()  # nothing after the final newline: not a line
     return [tuple(lines[4 * i:4 * i + 4]) for i in range(len(lines) // 4)]
+
+
+# ---- FusionMapper::filter_matches minus remove_alignables, and the order of sort_matches
+# (fusion_mapper.rs:276-384, read_match.rs:203-228), from their description.
+
+def low_complexity(s: str) -> bool:
+    return len(s) < 20 or sum(1 for a, b in zip(s, s[1:]) if a != b) < 7
+
+
+def match_filter(seq: str, read_break: int, left, right, left_distance: int, right_distance: int,
+                 deletion_threshold: int = 50) -> int:
+    """left/right = (contig, position).  0 kept, 1 complexity, 2 distance, 3 indel."""
+    if low_complexity(seq[:read_break + 1]) or low_complexity(seq[read_break + 1:]):
+        return 1
+    if left_distance + right_distance >= 5:
+        return 2
+    if left[0] == right[0] and abs(left[1] - right[1]) < deletion_threshold:
+        return 3
+    return 0
+
+
+def match_sort(matches):
+    """matches: (read_break, read_len, name bytes, payload).  Descending by the ReadMatch
+    order = read_break descending, read length ascending, name descending."""
+    out = sorted(matches, key=lambda m: m[2], reverse=True)          # name descending (stable)
+    out = sorted(out, key=lambda m: m[1])                             # length ascending
+    return sorted(out, key=lambda m: m[0], reverse=True)              # read_break descending

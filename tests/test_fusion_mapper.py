@@ -152,3 +152,41 @@ def test_fusion_mapper_end_to_end(gpu_device, oracle):
         st, rm = oracle.fusion_map_read(ox, g["reversed"], read, ox.map_read(read))
         assert (single is not None) == (st == 2) and mapable == (st != 0)
     ix.close()
+
+
+def test_filter_matches_and_sort_order():
+    """fusion_mapper.rs:276-384 without remove_alignables: the product's predicates against the
+    independent model on seeded matches that reach every reason, and the sort order on ties."""
+    from genefuserust_amd import FusionMapper, ReadMatch
+    from genefuserust_amd.indexer import GenePos
+    rng = np.random.default_rng(4)
+    fm = FusionMapper.__new__(FusionMapper)   # the predicates need no index
+    ms, want = [], []
+    for k in range(600):
+        ln = int(rng.integers(40, 160))
+        seq = rand_seq(rng, ln)
+        if k % 5 == 0:   # low-complexity flank: a homopolymer run on one side
+            cut = int(rng.integers(20, ln - 20))
+            seq = (b"A" * cut + seq[cut:]) if k % 2 else (seq[:cut] + b"AC" * 3 + b"T" * (ln - cut - 6))
+        brk = int(rng.integers(0, ln - 1)) if k % 7 else int(rng.choice([5, ln - 8]))
+        lc, rc_ = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        lp = int(rng.integers(-3000, 3000))
+        rp = lp + int(rng.integers(-80, 80)) if k % 3 == 0 else int(rng.integers(-3000, 3000))
+        ld, rd = int(rng.integers(-2, 5)), int(rng.integers(-2, 5))
+        m = ReadMatch(seq, brk, GenePos(lc, lp), GenePos(rc_, rp), 0, ld, rd, False, b"@r%d" % int(rng.integers(0, 50)))
+        ms.append(m)
+        want.append(M.match_filter(seq.decode(), brk, (lc, lp), (rc_, rp), ld, rd, 50))
+    kept, removed = fm.filter_matches(ms, 50)
+    assert [m for m, w in zip(ms, want) if w == 0] == kept
+    assert removed == {"complexity": want.count(1), "distance": want.count(2), "indels": want.count(3)}
+    assert min(removed.values()) > 10 and len(kept) > 10
+    got = FusionMapper.sort_matches(ms)
+    exp = M.match_sort([(m.m_read_break, len(m.m_read), m.m_name, i) for i, m in enumerate(ms)])
+    assert [(g.m_read_break, len(g.m_read), g.m_name) for g in got] == [(e[0], e[1], e[2]) for e in exp]
+    # known answers: break first, then the shorter read, then the larger name
+    a = ReadMatch(b"A" * 50, 30, GenePos(0, 1), GenePos(1, 1), 0, 0, 0, False, b"x")
+    b = ReadMatch(b"A" * 40, 30, GenePos(0, 1), GenePos(1, 1), 0, 0, 0, False, b"a")
+    c = ReadMatch(b"A" * 40, 30, GenePos(0, 1), GenePos(1, 1), 0, 0, 0, False, b"b")
+    d = ReadMatch(b"A" * 90, 31, GenePos(0, 1), GenePos(1, 1), 0, 0, 0, False, b"a")
+    assert [m.m_name + bytes([len(m.m_read)]) for m in FusionMapper.sort_matches([a, b, c, d])] == \
+        [b"a" + bytes([90]), b"b" + bytes([40]), b"a" + bytes([40]), b"x" + bytes([50])]
