@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 #pragma unroll
           for (int k = 0; k < NT; ++k) pp[k] = 0;
 #ifndef GF_SV_NO_INLINE_FILTER
-          if (K == GF_NONE_LIN && T.bloom_in_l2) {
+          if (K == GF_NONE_LIN && T.bloom_in_l2 == 2) {
             filt_done = true;
             int npos = 0, rem = nvalid;
             uint32_t wlo = gf_cut_pk(s_pk, w0, sh, 0);

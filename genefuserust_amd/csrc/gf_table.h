@@ -79,7 +79,8 @@ struct GfTable {
   // 4 MiB L2 of each XCD, where a lookup costs a fraction of an L2-missing bucket probe.
   const uint32_t* bloom;
   uint32_t bloom_words;     // 0 = filter disabled
-  uint32_t bloom_in_l2;     // 1 = small enough to live in L2: also worth asking for the seeds
+  uint32_t bloom_in_l2;     // 1 = (mostly) L2 hits: also worth asking for the seeds; 2 = fits an XCD's L2:
+                            //     seed+verify runs the filter pass for reads without a candidate itself
   uint32_t nbuckets;
   int32_t n_genes;
 };

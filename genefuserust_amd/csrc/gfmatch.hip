@@ -360,10 +360,11 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     GF_HIP(hipGetLastError());
   }
   // presence filter over canonical 14-mers.  Indexes up to ~14 M keys: <= GF_BLOOM_KIB (default
-  // 3 MiB) so that it lives in every XCD's L2.  Up to ~38 M keys: 1.75 bits per key, up to
-  // GF_BLOOM_MID_KIB (default 8 MiB) — no longer L2-resident, but still mostly L2 hits, and
-  // measured faster than the next form (IDX-C, 29 M keys: 4.04 vs 3.71 G reads/s; at 10 MiB and
-  // beyond the inline filter pass of seed+verify starts to lose).  Larger indexes: about
+  // 3 MiB) so that it lives in every XCD's L2, and seed+verify runs the filter pass for reads
+  // without a candidate diagonal itself.  Up to ~38 M keys: 1.75 bits per key, up to
+  // GF_BLOOM_MID_KIB (default 8 MiB) — no longer L2-resident, but still mostly L2 hits: used for
+  // the seeds and by the filter kernel (IDX-C, 29 M keys: 4.26 G reads/s; 4.13 with the inline
+  // filter pass, 3.71 with the next form).  Larger indexes: about
   // GF_BLOOM_BIG_BPK (default 4) bits per key, resident in the Infinity Cache and used by the
   // filter kernel only — a lookup is then an L2-missing request like a bucket probe, but one
   // lookup answers for two windows and a negative answer spares both bucket probes.
@@ -378,7 +379,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     const uint64_t want_words = keys * 7 / 128;  // 1.75 bits per key
     uint64_t words = std::min(std::max<uint64_t>(1024, keys / 2), cap_words);  // up to 16 bits per key
     if (kib > 0 && want_words <= cap_words) {
-      bloom_in_l2 = 1;
+      bloom_in_l2 = 2;
     } else if (kib > 0 && want_words <= mid_words) {
       words = want_words;
       bloom_in_l2 = 1;
