@@ -618,8 +618,10 @@ __device__ __forceinline__ void gf_convert16(const uint4& q, uint32_t& code32, u
   // table bytes: code 0 'A', 1 'C', 2 'T', 3 'G'
   const uint32_t d0 = q.x ^ __builtin_amdgcn_perm(0u, 0x47544341u, y0), d1 = q.y ^ __builtin_amdgcn_perm(0u, 0x47544341u, y1);
   const uint32_t d2 = q.z ^ __builtin_amdgcn_perm(0u, 0x47544341u, y2), d3 = q.w ^ __builtin_amdgcn_perm(0u, 0x47544341u, y3);
-  code32 = ((y0 * 0x01041040u) >> 24) | (((y1 * 0x01041040u) >> 24) << 8) | (((y2 * 0x01041040u) >> 24) << 16) |
-           (((y3 * 0x01041040u) >> 24) << 24);
+  // codes of 4 bases -> 8 bits: one dot product of the four bytes with (1, 4, 16, 64)
+  code32 = __builtin_amdgcn_udot4(y0, 0x40100401u, 0u, false) | (__builtin_amdgcn_udot4(y1, 0x40100401u, 0u, false) << 8) |
+           (__builtin_amdgcn_udot4(y2, 0x40100401u, 0u, false) << 16) |
+           (__builtin_amdgcn_udot4(y3, 0x40100401u, 0u, false) << 24);
   bad16 = 0;
   if (d0 | d1 | d2 | d3) {
     // bit 7 of each byte = that byte differs; gathered to one bit per base
