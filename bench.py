@@ -65,8 +65,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="first pass: 0 flat pipeline (default), 1 wave-per-read probe-all, 2 wave-per-read seed+verify, "
-                    "3 flat pipeline with a separate pack kernel")
+    ap.add_argument("--variant", type=int, default=0, help="first pass: 0 flat pipeline (default), 1 wave-per-read probe-all, 2 wave-per-read seed+verify")
     args = ap.parse_args()
 
     import numpy as np
@@ -187,7 +186,7 @@ def main() -> None:
     # per-kernel durations of the flat pipeline (HIP events inside the library, launch stream),
     # taken on extra steps outside the timed region
     stage_ms = None
-    if args.variant in (0, 3):
+    if args.variant == 0:
         ix.set_profiling(True)
         acc = [0.0, 0.0, 0.0, 0.0]
         reps = 5
@@ -196,8 +195,7 @@ def main() -> None:
             ms = ix.last_stage_ms()
             acc = [a + b for a, b in zip(acc, ms)]
         ix.set_profiling(False)
-        names = (["gf_k_pack", "gf_k_seedverify", "gf_k_probe", "gf_k_map_reads_list"] if args.variant == 3 else
-                 ["gf_k_seedverify_stream", "gf_k_probe_filter", "gf_k_probe_buckets", "gf_k_map_reads_list"])
+        names = ["gf_k_seedverify_stream", "gf_k_probe_filter", "gf_k_probe_buckets", "gf_k_map_reads_list"]
         stage_ms = {k: round(a / reps, 4) for k, a in zip(names, acc) if k}
 
     total_reads = n * world * args.steps
@@ -262,9 +260,7 @@ def main() -> None:
             "kernel": {0: "gf_map_reads_device = 4 kernels: gf_k_seedverify_stream + gf_k_probe_filter + "
                           "gf_k_probe_buckets + gf_k_map_reads_list; achieved uses their summed duration",
                        1: "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
-                       2: "gf_k_map_reads_short<4,1> (wave per read, seed+verify)",
-                       3: "gf_map_reads_device = 4 kernels: gf_k_pack + gf_k_seedverify + gf_k_probe + "
-                          "gf_k_map_reads_list; achieved uses their summed duration"}[args.variant],
+                       2: "gf_k_map_reads_short<4,1> (wave per read, seed+verify)"}[args.variant],
             "stage_ms": stage_ms,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

@@ -1,37 +1,33 @@
-// Flat ("thread per read") form of Indexer::map_read's first pass for reads of up
-// to 256 bases — same exact decisions as gf_map_kernels.h, far fewer instructions.
+// Flat ("thread per read") form of Indexer::map_read's first pass for reads of up to 320
+// bases — same exact decisions as gf_map_kernels.h, far fewer instructions.
 //
-// The wave-per-read kernel spends ~640 wave-instructions per read, most of them
-// wave-uniform bookkeeping (ballots, scalar branches, LDS staging) that serve one
-// read at a time; at 1.6 G reads/s the scalar/vector issue ports, not memory, are
-// the limit.  Here every lane owns a read, so the same bookkeeping is ordinary
-// per-lane arithmetic shared by 64 reads per instruction:
+// The wave-per-read kernel spends thousands of wave-instructions per read, most of them
+// wave-uniform bookkeeping (ballots, scalar branches, LDS staging) that serve one read at a
+// time.  Here every lane owns a read, so the same bookkeeping is ordinary per-lane
+// arithmetic shared by 64 reads per instruction:
 //
-//   K_pack        thread per 16 bytes of the batch: ASCII -> one packed stream in HBM
-//                 (2 bits per base, plus 1 "not A/C/G/T" bit per base), coalesced
-//                 16-byte loads, no per-read layout: a read's words are cut out of
-//                 the stream with funnel shifts by whoever needs them.
-//   K_seedverify  thread per read: up to 4 seed probes (2, then 2 more only when the
-//                 first two named no diagonal), each behind the L2-resident presence
-//                 filter; each UNIQUE seed hit names a candidate diagonal K, which is
-//                 verified against both strands of the genes laid out in site-code
-//                 space (gf_table.h: gdu) with word-parallel bit tricks (16 bases per
-//                 XOR): window i counts for K iff its 16 bases equal the bases of site
-//                 K+i and that site is the only site of its key.  Then the exact bound
-//                 of gf_map_kernels.h ("a diagonal gets at most one vote per window
-//                 that can still vote"):
-//                   v1 + open < 20 or v2 + open < 10  ->  []   (decided, nothing probed)
-//                 otherwise the read goes to K_probe with (v1, v2, windows to probe).
-//   K_probe       thread per undecided read.  Phase 1 asks the presence filter about every
-//                 unverified window, two windows per lookup (they share a 14-mer; L2 hits
-//                 only): a window the filter rules out cannot vote, so with P windows left
-//                 v1 + P < 20 or v2 + P < 10 -> [].  Phase 2
-//                 probes the P remaining windows one by one (one 64-byte bucket each),
-//                 h = windows that voted; stops as soon as v1 + h + left < 20 or
-//                 v2 + h + left < 10 -> [].
-//                 Reads that survive (junction reads, repeats) go to the list for
-//   K_full        the wave-per-read kernel (gf_k_map_reads_list), which recomputes the
-//                 read from scratch — votes, top two, gate, second pass, segments.
+//   gf_k_seedverify_stream  thread per read, packing fused in: each wavefront converts the
+//                 contiguous bytes of its next 64 reads to 2 bits per base (+ 1 "not A/C/G/T"
+//                 bit) straight into its own LDS tile; up to 4 seeds behind the presence
+//                 filter, probed one at a time until one names a candidate diagonal K, which
+//                 is verified against both strands of the genes laid out in site-code space
+//                 (gf_table.h: gdu) with word-parallel bit tricks (16 bases per XOR): window i
+//                 counts for K iff its 16 bases equal the bases of site K+i and that site is
+//                 the only site of its key.  Then the exact bound ("a diagonal gets at most
+//                 one vote per window that can still vote"):
+//                   v1 + open < 20 or open < 10  ->  []   (decided, nothing probed)
+//                 A read without a candidate goes through the presence filter right here
+//                 (two windows per look-up, L2 hits); with P windows left, P < 20 -> [].
+//                 Undecided reads are appended, with their packed words, to a list.
+//   gf_k_probe_filter  thread per undecided read that has a candidate: the same filter pass
+//                 over its unverified windows: v1 + P < 20 or v2 + P < 10 -> []; what is left
+//                 is compacted in place.
+//   gf_k_probe_buckets  thread per remaining read: probes the P windows' buckets (one 64-byte
+//                 bucket each), h = windows that voted; stops as soon as
+//                 v1 + h + left < 20 or v2 + h + left < 10 -> [].
+//   gf_k_map_reads_list  survivors (junction reads, repeats) and reads beyond 320 bases: the
+//                 exact wave-per-read kernel recomputes the read from scratch — votes, top
+//                 two, gate, second pass, segments.
 // Every read that ends here with [] was *proved* to fail the gate of
 // indexer.rs:353-360; everything else is computed by the exact kernel.
 #pragma once
@@ -46,61 +42,6 @@
 #define GF_PROBE_NT false
 #endif
 
-struct GfStream {
-  const uint32_t* pkg;  // word t = bases 16t..16t+15 of the stream, 2 bits each
-  const uint32_t* ivg;  // bit p = base p of the stream is not one of A,C,G,T
-  uint64_t cap_bases;   // bases covered by the two arrays
-};
-
-struct GfPipeEntry {  // one undecided read handed from K_seedverify to K_probe (32 B)
-  uint32_t read;      // read index in the batch
-  uint32_t v1v2;      // v1 | v2 << 8
-  uint32_t todo[4];   // bit w = stride-2 window w is clean and not verified: probe it
-  uint32_t pad[2];
-};
-
-// stream position 0 = the 16-byte aligned address at or below the first read
-__device__ __forceinline__ uintptr_t gf_stream_origin(const uint8_t* bases, const int64_t* offsets) {
-  return (uintptr_t)(bases + offsets[0]) & ~(uintptr_t)15;
-}
-
-// 4 ASCII bases (little-endian dword) -> 8 code bits (2 per base) and 4 "bad" bits.
-// Valid bases are exactly 'A','C','G','T' (indexer.rs:825-841).
-__device__ __forceinline__ void gf_convert4_bits(uint32_t x, uint32_t& code8, uint32_t& bad4) {
-  uint32_t y = (x >> 1) & 0x03030303u;
-  code8 = (y * 0x01041040u) >> 24;
-  uint32_t bad = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    uint32_t b = (x >> (8 * j)) & 0xFFu;
-    uint32_t v = (((b & 0xE0u) == 0x40u) ? 1u : 0u) & (0x0010008Au >> (b & 31u));
-    bad |= (v ^ 1u) << j;
-  }
-  bad4 = bad;
-}
-
-// ---- K_pack: thread per 16 bytes of the batch ----
-__global__ __launch_bounds__(256) void gf_k_pack(const uint8_t* __restrict__ bases,
-                                                 const int64_t* __restrict__ offsets, int64_t n,
-                                                 uint64_t cap_chunks, uint32_t* __restrict__ pkg,
-                                                 uint16_t* __restrict__ ivg16) {
-  const uintptr_t a0 = gf_stream_origin(bases, offsets);
-  const uintptr_t end = (uintptr_t)(bases + offsets[n]);
-  uint64_t chunks = end > a0 ? (uint64_t)((end - a0 + 15) >> 4) : 0;
-  if (chunks > cap_chunks) chunks = cap_chunks;
-  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < chunks;
-       t += (uint64_t)gridDim.x * blockDim.x) {
-    const uint4 q = *(const uint4*)(a0 + 16 * t);
-    uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
-    gf_convert4_bits(q.x, c0, b0);
-    gf_convert4_bits(q.y, c1, b1);
-    gf_convert4_bits(q.z, c2, b2);
-    gf_convert4_bits(q.w, c3, b3);
-    pkg[t] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-    ivg16[t] = (uint16_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12));
-  }
-}
-
 // 16 flag bits -> the same flags at the even bit positions of a word (2-bit layout)
 __device__ __forceinline__ uint32_t gf_spread16(uint32_t x) {
   x &= 0xFFFFu;
@@ -111,57 +52,6 @@ __device__ __forceinline__ uint32_t gf_spread16(uint32_t x) {
   return x;
 }
 
-// A read's words cut out of the stream: pk[j] = bases 16j..16j+15 of the read (2 bits
-// each), iv[j] = unusable-base flags in the same layout (not A/C/G/T, or beyond the end).
-template <int PW>
-__device__ __forceinline__ void gf_load_read_words(const GfStream& S, uint64_t pos, int L, uint32_t (&pk)[PW],
-                                                   uint32_t (&iv)[PW]) {
-  constexpr int IW = (PW + 1) / 2;
-  const uint64_t w0 = pos >> 4;
-  const uint32_t sh = 2u * (uint32_t)(pos & 15u);
-  uint32_t raw[PW + 1];
-#pragma unroll
-  for (int j = 0; j < PW + 1; ++j) raw[j] = S.pkg[w0 + j];
-#pragma unroll
-  for (int j = 0; j < PW; ++j) pk[j] = sh ? ((raw[j] >> sh) | (raw[j + 1] << (32u - sh))) : raw[j];
-  const uint64_t v0 = pos >> 5;
-  const uint32_t vs = (uint32_t)(pos & 31u);
-  uint32_t rv[IW + 1];
-#pragma unroll
-  for (int j = 0; j < IW + 1; ++j) rv[j] = S.ivg[v0 + j];
-#pragma unroll
-  for (int j = 0; j < IW; ++j) {
-    uint32_t b = vs ? ((rv[j] >> vs) | (rv[j + 1] << (32u - vs))) : rv[j];
-    // bases at or beyond the end of the read are unusable
-    const int k = L - 32 * j;
-    if (k < 32) b |= k <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << k);
-    iv[2 * j] = gf_spread16(b);
-    if (2 * j + 1 < PW) iv[2 * j + 1] = gf_spread16(b >> 16);
-  }
-}
-
-// For a stream z (bit 2p set = base p is bad), bit 2p of result word j is set iff
-// bases p .. p+15 are all good ("a clean window starts at p"); bases beyond the last
-// word count as bad.
-template <int PW>
-__device__ __forceinline__ void gf_clean_windows(const uint32_t (&z)[PW], uint32_t (&out)[PW]) {
-  uint32_t g[PW + 1];
-#pragma unroll
-  for (int j = 0; j < PW; ++j) g[j] = ~z[j] & 0x55555555u;
-  g[PW] = 0;
-  // runs of 2, 4, 8, 16 good bases by doubling (funnel shifts across words)
-#pragma unroll
-  for (int s = 1; s <= 8; s <<= 1) {
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-      const uint32_t sh = 2u * s;  // bits
-      g[j] &= (g[j] >> sh) | (g[j + 1] << (32u - sh));
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < PW; ++j) out[j] = g[j];
-}
-
 // every 4th bit (bits 0,4,..,28) of x gathered into the low 8 bits
 __device__ __forceinline__ uint32_t gf_gather_nibble_lsb(uint32_t x) {
   x &= 0x11111111u;
@@ -169,22 +59,6 @@ __device__ __forceinline__ uint32_t gf_gather_nibble_lsb(uint32_t x) {
   x = (x | (x >> 6)) & 0x000F000Fu;
   x = (x | (x >> 12)) & 0xFFu;
   return x;
-}
-
-// first bucket of a lookup whose loads were issued by the caller (several in flight)
-__device__ __forceinline__ uint32_t gf_match_bucket(uint4 q0, uint4 q1, uint4 q2, uint4 q3, uint32_t key,
-                                                    bool& overflow) {
-  uint32_t r = 0;
-  r = (q0.y == key && (q0.x & GF_VAL_LOW)) ? q0.x : r;
-  r = (q0.w == key && (q0.z & GF_VAL_LOW)) ? q0.z : r;
-  r = (q1.y == key && (q1.x & GF_VAL_LOW)) ? q1.x : r;
-  r = (q1.w == key && (q1.z & GF_VAL_LOW)) ? q1.z : r;
-  r = (q2.y == key && (q2.x & GF_VAL_LOW)) ? q2.x : r;
-  r = (q2.w == key && (q2.z & GF_VAL_LOW)) ? q2.z : r;
-  r = (q3.y == key && (q3.x & GF_VAL_LOW)) ? q3.x : r;
-  r = (q3.w == key && (q3.z & GF_VAL_LOW)) ? q3.z : r;
-  overflow = !r && (q0.x & GF_VAL_OVF);
-  return r & GF_VAL_LOW;
 }
 
 // wave-aggregated append: returns this lane's slot when `want`, one atomic per wave
@@ -211,324 +85,14 @@ __device__ __forceinline__ unsigned int gf_wave_append_lds(bool want, unsigned i
   return base + (unsigned int)gf_lanes_below(m);
 }
 
-// ---- K_seedverify: thread per read ----
-// Block b owns the reads [b*per_block, (b+1)*per_block) and the same range of list_b:
-// its undecided reads are appended there through an LDS counter (a single global
-// counter would serialise ~300 K wave-level atomics per launch at ~90 per microsecond),
-// and blk_cnt[b] tells K_probe's block b how many entries to take.
-template <int PW>
-__global__ __launch_bounds__(256) void gf_k_seedverify(GfTable T, GfStream S, const uint8_t* __restrict__ bases,
-                                                       const int64_t* __restrict__ offsets, int64_t n,
-                                                       int lmax, int mark_too_long,
-                                                       uint8_t* __restrict__ counts,
-                                                       GfPipeEntry* __restrict__ list_b,
-                                                       unsigned int* __restrict__ blk_cnt,
-                                                       int64_t per_block, uint32_t* __restrict__ list_c,
-                                                       unsigned int* __restrict__ ctr) {
-  __shared__ unsigned int s_cnt;
-  if (threadIdx.x == 0) s_cnt = 0;
-  __syncthreads();
-  const uintptr_t a0 = gf_stream_origin(bases, offsets);
-  const int64_t r_lo = (int64_t)blockIdx.x * per_block;
-  const int64_t r_hi = r_lo + per_block < n ? r_lo + per_block : n;
-  GfPipeEntry* my_list = list_b + r_lo;
-  // whole waves reach the ballots: iterate in steps of the block size over a rounded range
-  for (int64_t r = r_lo + threadIdx.x; r < r_lo + ((per_block + 255) & ~(int64_t)255); r += blockDim.x) {
-    const bool in_range = r < r_hi;
-    bool undecided = false, to_full = false;
-    uint32_t e_v1v2 = 0, e_todo[4] = {0, 0, 0, 0};
-    if (in_range) {
-      const int64_t off0 = offsets[r];
-      const int64_t len64 = offsets[r + 1] - off0;
-      const uint64_t pos = (uint64_t)((uintptr_t)(bases + off0) - a0);
-      if (len64 > lmax) {
-        if (mark_too_long) counts[r] = GF_COUNT_TOO_LONG;  // else: a longer class owns this read
-      } else if (len64 < GF_KMER + 2 * (GF_MAJOR_KEYS / 2 - 1)) {
-        counts[r] = 0;  // fewer than 20 stride-2 windows: count1 < 20 whatever they hit
-      } else if (pos + (uint64_t)len64 + 64 > S.cap_bases) {
-        to_full = true;  // outside the packed stream (gaps between reads): exact kernel
-      } else {
-        const int L = (int)len64;
-        uint32_t pk[PW], iv[PW];
-        gf_load_read_words<PW>(S, pos, L, pk, iv);
-#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 1
-        { uint32_t a = 0; for (int j = 0; j < PW; ++j) a ^= pk[j] ^ iv[j]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
-#endif
-
-        // clean stride-2 windows of the read (all 16 bases usable): bit 4t of word j = window 8j+t
-        uint32_t cw[PW];
-        gf_clean_windows<PW>(iv, cw);
-        int nvalid = 0;
-#pragma unroll
-        for (int j = 0; j < PW; ++j) nvalid += __popc(cw[j] & 0x11111111u);
-#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 2
-        { uint32_t a = nvalid; for (int j = 0; j < PW; ++j) a ^= pk[j]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
-#endif
-
-        // seeds at bases 0, 32, 64, 96 (word aligned: the key is one word).  All four go
-        // through the presence filter together (L2 hits).
-        uint32_t cand[4] = {GF_NONE_LIN, GF_NONE_LIN, GF_NONE_LIN, GF_NONE_LIN};
-        {
-          uint32_t key[4];
-          bool ok[4];
-          uint32_t fw[4], fb[4];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int wj = 2 * s < PW ? 2 * s : 0;
-            key[s] = pk[wj];
-            ok[s] = (2 * s < PW) && (cw[wj] & 1u);
-            if (T.bloom_in_l2) {
-              const uint32_t h2 = GF_BLOOM_HASH((key[s] >> 4));  // the window's last 14 bases
-              fb[s] = GF_BLOOM_BITS(h2);
-              fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // unconditional: always in range
-            }
-          }
-          if (T.bloom_in_l2) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) ok[s] = ok[s] && (fw[s] & fb[s]) == fb[s];
-          }
-#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 3
-          { uint32_t a = nvalid + ok[0] + 2 * ok[1] + 4 * ok[2] + 8 * ok[3]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
-#endif
-          // one bucket probe at a time, in seed order, until one names a diagonal: an
-          // on-target read costs one L2-missing request here, not two
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            bool have = false;
-#pragma unroll
-            for (int s2 = 0; s2 < s; ++s2) have = have || cand[s2] != GF_NONE_LIN;
-            if (ok[s] && !have) {
-              const uint32_t val = gf_lookup(T, key[s]);
-              if ((val >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) cand[s] = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
-            }
-          }
-        }
-
-        // verify each distinct candidate diagonal
-        int v1 = 0, v2 = 0, nver = 0;
-        uint32_t vm[PW];  // verified windows, same sparse layout as cw
-#pragma unroll
-        for (int j = 0; j < PW; ++j) vm[j] = 0;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          bool fresh = cand[s] != GF_NONE_LIN;
-#pragma unroll
-          for (int s2 = 0; s2 < s; ++s2) fresh = fresh && cand[s2] != cand[s];
-          if (fresh) {
-            const uint32_t K = cand[s];
-            const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
-            const uint32_t bo = 2u * (K & 15u);
-            uint32_t gdr[PW + 1], ubr[PW + 1];
-#pragma unroll
-            for (int j = 0; j < PW + 1; ++j) {
-              const uint2 v = gp[j];
-              gdr[j] = v.x;
-              ubr[j] = v.y;
-            }
-            uint32_t zz[PW], cl[PW];
-#pragma unroll
-            for (int j = 0; j < PW; ++j) {
-              const uint32_t g = bo ? ((gdr[j] >> bo) | (gdr[j + 1] << (32u - bo))) : gdr[j];
-              const uint32_t x = pk[j] ^ g;
-              zz[j] = ((x | (x >> 1)) & 0x55555555u) | iv[j];  // mismatching or unusable base
-            }
-            gf_clean_windows<PW>(zz, cl);
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < PW; ++j) {
-              const uint32_t u = bo ? ((ubr[j] >> bo) | (ubr[j + 1] << (32u - bo))) : ubr[j];
-              const uint32_t ver = cl[j] & u & 0x11111111u & ~vm[j];
-              vm[j] |= ver;
-              cnt += __popc(ver);
-            }
-            nver += cnt;
-            if (cnt > v1) { v2 = v1; v1 = cnt; } else if (cnt > v2) { v2 = cnt; }
-          }
-        }
-
-#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 5
-        { uint32_t a = nvalid ^ v1 ^ (v2 << 8) ^ nver; for (int j = 0; j < PW; ++j) a ^= vm[j]; counts[r] = (uint8_t)(a == 0x1234567u); continue; }
-#endif
-        // every other diagonal gets at most one vote per window that can still vote
-        const int open = nvalid - nver;
-        if (v1 + open < GF_MAJOR_KEYS / 2 || v2 + open < GF_MINOR_KEYS / 2) {
-          counts[r] = 0;
-        } else {
-          undecided = true;
-          e_v1v2 = (uint32_t)v1 | ((uint32_t)v2 << 8);
-#pragma unroll
-          for (int j = 0; j < PW; ++j)
-            e_todo[j >> 2] |= gf_gather_nibble_lsb(cw[j] & ~vm[j]) << (8 * (j & 3));
-        }
-      }
-    }
-    const unsigned int slot_b = gf_wave_append_lds(undecided, &s_cnt);
-    if (undecided) {
-      GfPipeEntry e;
-      e.read = (uint32_t)r;
-      e.v1v2 = e_v1v2;
-      e.todo[0] = e_todo[0]; e.todo[1] = e_todo[1]; e.todo[2] = e_todo[2]; e.todo[3] = e_todo[3];
-      e.pad[0] = e.pad[1] = 0;
-      my_list[slot_b] = e;
-    }
-    const unsigned int slot_c = gf_wave_append(to_full, ctr + 1);  // rare
-    if (to_full) list_c[slot_c] = (uint32_t)r;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt;
-}
-
-// ---- K_probe: thread per undecided read ----
-template <int PW>
-__global__ __launch_bounds__(256) void gf_k_probe(GfTable T, GfStream S, const uint8_t* __restrict__ bases,
-                                                  const int64_t* __restrict__ offsets,
-                                                  const GfPipeEntry* __restrict__ list_b,
-                                                  const unsigned int* __restrict__ blk_cnt, int64_t per_block,
-                                                  uint8_t* __restrict__ counts, uint32_t* __restrict__ list_c,
-                                                  unsigned int* __restrict__ ctr) {
-  // the read's codes live in LDS for the duration of its probes ([word][thread]: each
-  // thread reads only its own column, conflict-free)
-  __shared__ uint32_t s_pk[(PW + 1) * 256];
-  const uintptr_t a0 = gf_stream_origin(bases, offsets);
-  // block b takes the entries K_seedverify's block b left in its region of list_b
-  const unsigned int nb = blk_cnt[blockIdx.x];
-  const GfPipeEntry* my_list = list_b + (int64_t)blockIdx.x * per_block;
-  const unsigned int nb_round = (nb + 63u) & ~63u;  // whole waves stay in the loop for the ballot
-  for (unsigned int t = threadIdx.x; t < nb_round; t += blockDim.x) {
-    bool to_full = false;
-    uint32_t r = 0;
-    if (t < nb) {
-      const GfPipeEntry e = my_list[t];
-      r = e.read;
-      const int v1 = (int)(e.v1v2 & 0xFFu), v2 = (int)((e.v1v2 >> 8) & 0xFFu);
-      uint32_t m0 = e.todo[0], m1 = e.todo[1], m2 = e.todo[2], m3 = e.todo[3];
-      int left = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
-      int h = 0;
-      uint32_t pk[PW + 1];
-      {
-        const uint64_t pos = (uint64_t)((uintptr_t)(bases + offsets[r]) - a0);
-        const uint64_t w0 = pos >> 4;
-        const uint32_t sh = 2u * (uint32_t)(pos & 15u);
-        uint32_t raw[PW + 1];
-#pragma unroll
-        for (int j = 0; j < PW + 1; ++j) raw[j] = S.pkg[w0 + j];
-#pragma unroll
-        for (int j = 0; j < PW; ++j) {
-          pk[j] = sh ? ((raw[j] >> sh) | (raw[j + 1] << (32u - sh))) : raw[j];
-          s_pk[j * 256 + threadIdx.x] = pk[j];  // phase 2 indexes the words dynamically
-        }
-        pk[PW] = 0;
-        s_pk[PW * 256 + threadIdx.x] = 0;
-      }
-      // A window can only vote if its key is in the table, so count1 <= v1 + (windows that
-      // can vote) and count2 <= v2 + (the same).  Phase 1 asks the L2-resident presence
-      // filter about every window (4 lookups in flight, no bucket touched): a clear bit
-      // pair proves the window cannot vote.  Most undecided reads die here.
-      uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // windows the filter could not rule out
-      bool dead = false;
-      if (T.bloom_words) {
-        // windows 2q and 2q+1 share the 14-mer at bases 4q+2 .. 4q+15: one lookup for both.
-        // Fully unrolled over the pairs (compile-time shifts on the words in registers),
-        // four look-ups in flight per step.
-        const uint32_t td[4] = {m0, m1, m2, m3};
-        uint32_t pp[4] = {0, 0, 0, 0};
-        int npos = 0, rem = left;  // not ruled out so far / not asked yet
-#pragma unroll
-        for (int q0 = 0; q0 < 4 * PW; q0 += 4) {
-          if (!dead) {
-            uint32_t word[4], bits[4], both[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int q = q0 + u;
-              const int wbit = (2 * q) & 31, wword = (2 * q) >> 5;
-              both[u] = wword < 4 ? (td[wword] >> wbit) & 3u : 0u;
-              const int b0 = 4 * q + 2;  // first base of the shared 14-mer
-              const int j = b0 >> 4;
-              const uint32_t sh14 = 2u * (uint32_t)(b0 & 15);
-              const uint32_t s14 = ((pk[j] >> sh14) | (pk[j + 1] << (32u - sh14))) & 0x0FFFFFFFu;  // sh14 is never 0
-              const uint32_t h2 = GF_BLOOM_HASH((s14));
-              bits[u] = GF_BLOOM_BITS(h2);
-              word[u] = 0;
-              if (both[u]) word[u] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int q = q0 + u;
-              const int cnt = (int)(both[u] & 1u) + (int)(both[u] >> 1);
-              rem -= cnt;
-              if (both[u] && (word[u] & bits[u]) == bits[u]) {
-                pp[(2 * q) >> 5 < 4 ? (2 * q) >> 5 : 0] |= both[u] << ((2 * q) & 31);
-                npos += cnt;
-              }
-            }
-            // even if every window not asked yet could vote, the gate is out of reach
-            dead = (v1 + npos + rem < GF_MAJOR_KEYS / 2) || (v2 + npos + rem < GF_MINOR_KEYS / 2);
-          }
-        }
-        p0 = pp[0]; p1 = pp[1]; p2 = pp[2]; p3 = pp[3];
-      } else {
-        p0 = m0; p1 = m1; p2 = m2; p3 = m3;
-      }
-      left = __popc(p0) + __popc(p1) + __popc(p2) + __popc(p3);
-      // phase 2: the exact bucket probe of the remaining windows, one by one, stopping as
-      // soon as v1 + h + left < 20 or v2 + h + left < 10
-      dead = dead || (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
-      while (!dead && left > 0) {
-        // the read dies only after at least `need` more probes miss: issue that many (up to
-        // 4) bucket probes together instead of one round trip each
-        const int needA = v1 + h + left - (GF_MAJOR_KEYS / 2 - 1);
-        const int needB = v2 + h + left - (GF_MINOR_KEYS / 2 - 1);
-        int need = needA < needB ? needA : needB;
-        need = need < 1 ? 1 : (need > 4 ? 4 : need);
-        uint32_t key[4];
-        bool act[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          act[u] = u < need && (p0 | p1 | p2 | p3);
-          int w = 0;
-          if (act[u]) {
-            if (p0) { w = __builtin_ctz(p0); p0 &= p0 - 1; }
-            else if (p1) { w = 32 + __builtin_ctz(p1); p1 &= p1 - 1; }
-            else if (p2) { w = 64 + __builtin_ctz(p2); p2 &= p2 - 1; }
-            else { w = 96 + __builtin_ctz(p3); p3 &= p3 - 1; }
-          }
-          const int j = w >> 3;
-          const uint32_t sh = 4u * (uint32_t)(w & 7);
-          const uint32_t lo = s_pk[j * 256 + threadIdx.x], hi = s_pk[(j + 1) * 256 + threadIdx.x];
-          key[u] = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
-        }
-        uint32_t ty[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (act[u]) ty[u] = gf_lookup<GF_PROBE_NT>(T, key[u]) >> GF_TYPE_SHIFT;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (act[u]) {
-            h += (ty[u] == GF_TYPE_UNIQUE || ty[u] == GF_TYPE_DUPES) ? 1 : 0;
-            left -= 1;
-          }
-        }
-        dead = (v1 + h + left < GF_MAJOR_KEYS / 2) || (v2 + h + left < GF_MINOR_KEYS / 2);
-      }
-      if (dead) counts[r] = 0;
-      else to_full = true;
-    }
-    const unsigned int slot = gf_wave_append(to_full, ctr + 1);
-    if (to_full) list_c[slot] = r;
-  }
-}
-
-// =====================================================================================
-// Fused form (default): K_pack folded into K_seedverify through LDS.
-//
-// Consecutive reads are consecutive bytes (read r = bases[offsets[r] .. offsets[r+1])), so
-// the next <= 256 reads of a block are one contiguous span.  The block converts that span
-// to the packed form with coalesced 16-byte loads straight into LDS, and each thread cuts
-// its read's words out of LDS.  Compared with the separate K_pack this removes the packed
-// stream's round trip through HBM (1.1 GB written + read per 20 M reads) and, more
-// important, ~17 dword gathers per read from it: those were L2 hits, but every one of them
-// is a request against the ~270 G/s L2 ceiling that the presence filter also lives on.
-// An undecided read's packed words travel to K_probe inside its list entry.
+// Packing is folded into seed+verify through LDS.  Consecutive reads are consecutive bytes
+// (read r = bases[offsets[r] .. offsets[r+1])), so the next 64 reads of a wavefront are one
+// contiguous span: it is converted with coalesced 16-byte loads straight into LDS, and each
+// thread cuts its read's words out of LDS.  (A separate packing kernel cost the packed
+// stream's round trip through HBM, 1.1 GB written + read per 20 M reads, and ~17 dword
+// gathers per read from it: L2 hits, but every one of them a request against the ~270 G/s L2
+// ceiling that the presence filter also lives on.)  An undecided read's packed words travel
+// to the later passes inside its list entry.
 // One undecided read: w[0] = read index in the batch, w[1] = v1 | v2 << 8, w[2 .. 2+NT) = one
 // bit per stride-2 window still to be asked (bit b of word k = window 32k + b), then the
 // read's PW words of 2-bit codes; padded to whole 16-byte vectors.

@@ -257,7 +257,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
 
   std::unique_ptr<gf_index> ix(new gf_index());
   ix->device = dev;
-  if (const char* e = getenv("GF_MAP_VARIANT")) ix->map_variant = atoi(e) >= 0 && atoi(e) <= 3 ? atoi(e) : 0;  // experiments
+  if (const char* e = getenv("GF_MAP_VARIANT")) ix->map_variant = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;  // experiments
   hipDeviceProp_t prop;
   GF_HIP(hipGetDeviceProperties(&prop, dev));
   ix->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -518,73 +518,6 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
                      : launch_flat<20>(idx, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev);
     if (wrc != GF_OK) return wrc;
     if (prof) mix->stages_recorded = true;
-  } else if (idx->map_variant == 3) {
-    // flat pipeline with a separate K_pack (kept for A/B measurements against the fused form)
-    const bool small = max_read_len <= 160;
-    const int lmax = top == 0 ? max_read_len : 256;
-    const int mark = top == 0 ? 1 : 0;
-    // packed stream: covers n * lmax bases from the first read on; reads that lie beyond
-    // it (batches with gaps between reads) are routed to the exact kernel
-    const uint64_t cap_chunks = ((uint64_t)n * (uint64_t)lmax + 15) / 16 + 8;
-    int blk_mult = 32;
-    if (const char* e = getenv("GF_NBLK_MULT")) blk_mult = std::max(1, atoi(e));  // experiments
-    const int nblk = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * blk_mult);
-    const int64_t per_block = (n + nblk - 1) / nblk;
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t sz_pkg = al((cap_chunks + 64) * sizeof(uint32_t));
-    const size_t sz_ivg = al((cap_chunks / 2 + 64) * sizeof(uint32_t));
-    const size_t sz_lb = al((size_t)n * sizeof(GfPipeEntry));
-    const size_t sz_lc = al((size_t)n * sizeof(uint32_t));
-    const size_t sz_bc = al((size_t)nblk * sizeof(unsigned int));
-    const size_t sz_ctr = 256;
-    const size_t need = sz_pkg + sz_ivg + sz_lb + sz_lc + sz_bc + sz_ctr;
-    std::lock_guard<std::mutex> ws_lock(mix->ws_mu);  // held until this call's launches are queued
-    void* ws_base = nullptr;
-    {
-      int wrc = acquire_workspace(mix, st, need, &ws_base);
-      if (wrc != GF_OK) return wrc;
-    }
-    uint8_t* wp = (uint8_t*)ws_base;
-    uint32_t* pkg = (uint32_t*)wp; wp += sz_pkg;
-    uint32_t* ivg = (uint32_t*)wp; wp += sz_ivg;
-    GfPipeEntry* list_b = (GfPipeEntry*)wp; wp += sz_lb;
-    uint32_t* list_c = (uint32_t*)wp; wp += sz_lc;
-    unsigned int* blk_cnt = (unsigned int*)wp; wp += sz_bc;
-    unsigned int* ctr = (unsigned int*)wp;
-    GF_HIP(hipMemsetAsync(ctr, 0, 64, st));
-    GfStream S;
-    S.pkg = pkg;
-    S.ivg = ivg;
-    S.cap_bases = cap_chunks * 16;
-    const int g_pack = (int)std::min<uint64_t>((cap_chunks + 255) / 256, (uint64_t)idx->n_cus * 64);
-    // K_seedverify block b and K_probe block b share the read range / list region b
-    const int g_full = idx->n_cus * 8;
-    if (prof) GF_HIP(hipEventRecord(mix->ev_stage[0], st));
-    hipLaunchKernelGGL(gf_k_pack, dim3(g_pack), dim3(256), 0, st, bases, offsets, n, cap_chunks, pkg, (uint16_t*)ivg);
-    if (prof) GF_HIP(hipEventRecord(mix->ev_stage[1], st));
-    if (small) {
-      constexpr int PW = 10;  // 16-base words of a read of up to 160 bases
-      hipLaunchKernelGGL((gf_k_seedverify<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, n, lmax,
-                         mark, counts, list_b, blk_cnt, per_block, list_c, ctr);
-      if (prof) GF_HIP(hipEventRecord(mix->ev_stage[2], st));
-      hipLaunchKernelGGL((gf_k_probe<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, list_b,
-                         blk_cnt, per_block, counts, list_c, ctr);
-    } else {
-      constexpr int PW = 16;  // up to 256 bases
-      hipLaunchKernelGGL((gf_k_seedverify<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, n, lmax,
-                         mark, counts, list_b, blk_cnt, per_block, list_c, ctr);
-      if (prof) GF_HIP(hipEventRecord(mix->ev_stage[2], st));
-      hipLaunchKernelGGL((gf_k_probe<PW>), dim3(nblk), dim3(256), 0, st, idx->table, S, bases, offsets, list_b,
-                         blk_cnt, per_block, counts, list_c, ctr);
-    }
-    if (prof) GF_HIP(hipEventRecord(mix->ev_stage[3], st));
-    hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(g_full), dim3(256), 0, st, idx->table, bases, offsets,
-                       list_c, (int64_t)1, ctr + 1, counts, matches);
-    GF_HIP(hipGetLastError());
-    if (prof) {
-      GF_HIP(hipEventRecord(mix->ev_stage[4], st));
-      mix->stages_recorded = true;
-    }
   } else {
     constexpr int W = 4;
     int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 8);
@@ -1124,7 +1057,7 @@ int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_by
 }
 
 int gf_set_map_variant(gf_index* idx, int32_t variant) {
-  if (!idx || variant < 0 || variant > 3) return fail(GF_ERR_ARG, "bad variant");
+  if (!idx || variant < 0 || variant > 2) return fail(GF_ERR_ARG, "bad variant");
   idx->map_variant = variant;
   return GF_OK;
 }

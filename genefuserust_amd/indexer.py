@@ -245,8 +245,7 @@ class Indexer:
         _lib.check(_lib.lib().gf_set_map_variant(self._handle(), int(variant)))
 
     def last_stage_ms(self):
-        """Flat pipeline: ms of its four kernels (seed+verify, filter, buckets, exact kernel; variant 3:
-        pack, seed+verify, probe, exact kernel)."""
+        """Flat pipeline: ms of its four kernels (seed+verify, filter, buckets, exact kernel)."""
         import ctypes as C
         out = (C.c_float * 4)()
         _lib.check(_lib.lib().gf_last_stage_ms(self._handle(), out))

@@ -267,12 +267,11 @@ int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_by
  * returns the duration of the most recent launch (negative if none). */
 int gf_set_profiling(gf_index* idx, int32_t on);
 
-/* First pass for short reads (up to 320 bases for 0, 256 for the others): 0 (default) = flat pipeline (thread per read:
- * pack + seed + verify in one kernel, probe the undecided, exact wave-per-read kernel
- * on the survivors), 1 = wave-per-read kernel probing every window, 2 = wave-per-read
- * kernel with seed + verify, 3 = the flat pipeline with packing as a separate kernel.
- * All are exact and return identical results; the switch exists for A/B timing and
- * for the tests that check exactly that. */
+/* First pass for short reads (up to 320 bases for 0, 256 for the others): 0 (default) = flat
+ * pipeline (thread per read: pack + seed + verify in one kernel, filter and bucket passes over
+ * the undecided, exact wave-per-read kernel on the survivors), 1 = wave-per-read kernel probing
+ * every window, 2 = wave-per-read kernel with seed + verify.  All are exact and return identical
+ * results; the switch exists for A/B timing and for the tests that check exactly that. */
 int gf_set_map_variant(gf_index* idx, int32_t variant);
 float gf_last_map_kernel_ms(gf_index* idx);
 

@@ -80,10 +80,10 @@ def test_index_content_every_key(branch_index, golden):
     assert not cnt.any()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_map_golden_cases(branch_index, golden, variant):
     """variant 0 = flat pipeline (pack fused into seed+verify), 1 = wave-per-read probe-all,
-    2 = wave-per-read seed+verify, 3 = flat pipeline with a separate pack kernel."""
+    2 = wave-per-read seed+verify."""
     branch_index.set_map_variant(variant)
     reads = [c["read"].encode() for c in golden["cases"]]
     got = branch_index.map_reads(reads)
@@ -220,7 +220,7 @@ def test_with_loaded_ref_constructor(gpu_device, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, "0-nofilter", "0-midfilter", "0-bigfilter"])
+@pytest.mark.parametrize("variant", [0, 1, 2, "0-nofilter", "0-midfilter", "0-bigfilter"])
 @pytest.mark.parametrize("shape,scale,n_reads", [("IDX-T", 0.02, 60000), ("IDX-C", 0.004, 60000)])
 def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, variant, monkeypatch):
     """Repeat-rich synthetic genes (2 % repeat family, N bases) and a junction-heavy
@@ -348,7 +348,7 @@ def test_full_size_properties(gpu_device, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3])
+@pytest.mark.parametrize("variant", [0, 2])
 def test_batches_with_gaps_and_mixed_lengths(branch_index, golden, oracle, variant):
     """Reads need not be packed back to back: gaps between reads (so that most of the
     batch lies beyond the packed stream of the flat pipeline), a first offset > 0, every
