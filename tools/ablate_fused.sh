@@ -2,10 +2,10 @@
 # Timing-only builds of the fused seed+verify kernel (ablations give wrong results by
 # construction; occupancy variants are exact).  build here, run on the GPU box.
 #   GF_ABLATE_SV: 1 = stage + cut words only, 3 = + presence filter, 4 = + seed probes (no verification)
-#   GF_SV_WAVES_PER_SIMD: register budget of the kernel
+#   GF_SVS_WAVES_PER_SIMD: register budget of the kernel
 set -e
 REPO=$(cd $(dirname $0)/.. && pwd)
-VARIANTS="sv1:-DGF_ABLATE_SV=1 sv3:-DGF_ABLATE_SV=3 sv4:-DGF_ABLATE_SV=4 r2:-DGF_SV_R2=2 r1:-DGF_SV_R2=1 w3:-DGF_SV_WAVES_PER_SIMD=3"
+VARIANTS="sv1:-DGF_ABLATE_SV=1 sv3:-DGF_ABLATE_SV=3 sv4:-DGF_ABLATE_SV=4 w4:-DGF_SVS_WAVES_PER_SIMD=4 w8:-DGF_SVS_WAVES_PER_SIMD=8"
 if [ "$1" = build ]; then
   for v in $VARIANTS; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 ${v#*:} -shared \
