@@ -187,11 +187,14 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __r
   const int in_tile = (int)((n_rec - t0) < GF_FQ_RTILE ? (n_rec - t0) : GF_FQ_RTILE);
   // each wavefront takes records wave, wave+4, ...; four records per round so that their
   // loads are in flight together (a record is one load-store round trip otherwise)
-  for (int i0 = wave; i0 < in_tile; i0 += 4 * (GF_CTHREADS / 64)) {
-    bool simple[4];
-    uint32_t slo[4], shi[4], qlo[4], qhi[4];
+#ifndef GF_FQ_INFLIGHT
+#define GF_FQ_INFLIGHT 4
+#endif
+  for (int i0 = wave; i0 < in_tile; i0 += GF_FQ_INFLIGHT * (GF_CTHREADS / 64)) {
+    bool simple[GF_FQ_INFLIGHT];
+    uint32_t slo[GF_FQ_INFLIGHT], shi[GF_FQ_INFLIGHT], qlo[GF_FQ_INFLIGHT], qhi[GF_FQ_INFLIGHT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GF_FQ_INFLIGHT; ++u) {
       const int i = i0 + u * (GF_CTHREADS / 64);
       simple[u] = false;
       if (i < in_tile) {
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __r
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GF_FQ_INFLIGHT; ++u) {
       const int i = i0 + u * (GF_CTHREADS / 64);
       if (i >= in_tile) continue;
       const int64_t dst = s_dst[i];

@@ -48,8 +48,7 @@ def fastq_cut_device(indexer: Indexer, text, stream=None) -> FastqBatch:
     st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
     ws = torch.empty(int(L.gf_fastq_workspace_bytes(n)), dtype=torch.uint8, device=dev)
     n_lines = torch.zeros(2, dtype=torch.int64, device=dev)
-    # every line of a record has at least its newline: at most n lines
-    cap = n // 2 + 4   # a FASTQ text has far fewer newlines than this; grown below if not
+    cap = n // 16 + 1024   # FASTQ lines average far more than 16 bytes; grown below if not
     nl_pos = torch.empty(cap, dtype=torch.int64, device=dev)
     _lib.check(L.gf_fastq_index_device(h, text.data_ptr(), n, nl_pos.data_ptr(), cap, n_lines.data_ptr(),
                                        ws.data_ptr(), st))
