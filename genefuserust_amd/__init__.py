@@ -5,7 +5,8 @@ Only the hot path lives here: index build + per-read seed mapping as HIP
 kernels for gfx950 (csrc/), the C ABI (include/gfmatch.h) and this host-side
 mirror of the reference interface.  See DESIGN.md.
 """
-from .indexer import Fusion, Gene, GenePos, Indexer, SeqMatch, resolve_gene_slice, unpack_matches  # noqa: F401
+from .indexer import (Exon, FastaReader, Fusion, Gene, GenePos, Indexer, SeqMatch, resolve_gene_slice,  # noqa: F401
+                      unpack_matches)
 from .fusion_mapper import FusionMapper, ReadMatch, edit_distance, reverse_complement  # noqa: F401
 from .read_pair import MergedRead, SequenceReadPair, fast_merge_batch, fast_merge_device, scan_pair_end  # noqa: F401
 from .fastq import FastqBatch, FastqReader, FastqReaderPair, fastq_cut_device, record_lines  # noqa: F401

@@ -11,7 +11,7 @@ compute goes through libgfmatch.so; there is no Python or CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Dict, List, Mapping, NamedTuple, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -39,25 +39,183 @@ class SeqMatch(NamedTuple):
 
 
 @dataclass
+class Exon:
+    """src/core/gene.rs:9-13"""
+    id: int
+    start: int
+    end: int
+
+
+@dataclass
 class Gene:
-    """The fields of src/core/gene.rs:16-23 that the Indexer reads."""
-    m_name: str
-    m_chr: str
-    m_start: int
-    m_end: int
+    """src/core/gene.rs:16-229: the gene line of a fusion CSV and its exons."""
+    m_name: str = "invalid"
+    m_chr: str = "invalid"
+    m_start: int = 0
+    m_end: int = 0
     m_reversed: bool = False
+    m_exons: List[Exon] = field(default_factory=list)
 
     def is_reversed(self) -> bool:
         return self.m_reversed
 
+    def valid(self) -> bool:  # gene.rs:39-41
+        return self.m_name != "invalid" and self.m_start != 0 and self.m_end != 0
+
+    @classmethod
+    def parse(cls, line_str: str) -> "Gene":
+        """gene.rs:43-88: ">NAME,chr:start-end"; anything short of that gives the invalid gene;
+        numbers that do not parse raise, like the reference's `?`."""
+        splitted = line_str.split(",")
+        if len(splitted) < 2:
+            return cls()
+        name = splitted[0][1:].strip()
+        chr_pos = splitted[1].split(":")
+        if len(chr_pos) < 2:
+            return cls()
+        rng = chr_pos[1].split("-")
+        if len(rng) < 2:
+            return cls()
+        return cls(name, chr_pos[0].strip(), _parse_i32(rng[0]), _parse_i32(rng[1]))
+
+    def add_exon(self, id_: int, start: int, end: int) -> None:  # gene.rs:90-105
+        self.m_exons.append(Exon(id_, start, end))
+        if len(self.m_exons) > 1 and self.m_exons[0].start > self.m_exons[1].start:
+            self.m_reversed = True
+
+    def get_exon_intron(self, pos: int) -> Tuple[Optional[bool], Optional[int]]:
+        """gene.rs:171-203: (is_exon, number); (None, None) when no exon or intron holds the
+        position (the reference leaves its out-parameters untouched)."""
+        pp = abs(pos) + self.m_start
+        for i, ex in enumerate(self.m_exons):
+            if ex.start <= pp <= ex.end:
+                return True, ex.id
+            if i > 0:
+                prev = self.m_exons[0]  # the reference never advances prev_exon: it stays the first exon
+                if self.m_reversed:
+                    if ex.end < pp < prev.start:
+                        return False, ex.id - 1
+                elif prev.end < pp < ex.start:
+                    return False, ex.id - 1
+        return None, None
+
+    def pos2str(self, pos: int) -> str:
+        """gene.rs:131-169, e.g. "ALK:exon:20|-chr2:29446222"."""
+        pp = abs(pos) + self.m_start
+        ss = self.m_name + ":"
+        for i, ex in enumerate(self.m_exons):
+            if ex.start <= pp <= ex.end:
+                ss += "exon:%d|" % ex.id
+                break
+            if i > 0:
+                prev = self.m_exons[i - 1]
+                if self.m_reversed:
+                    if ex.end < pp < prev.start:
+                        ss += "intron:%d|" % (ex.id - 1)
+                        break
+                elif prev.end < pp < ex.start:
+                    ss += "intron:%d|" % (ex.id - 1)
+                    break
+        return ss + ("+" if pos >= 0 else "-") + "%s:%d" % (self.m_chr, pp)
+
+    def gene_pos_2_chr_pos(self, genepos: int) -> int:  # gene.rs:205-212
+        chrpos = abs(genepos) + self.m_start
+        return -chrpos if genepos < 0 else chrpos
+
+
+def _parse_i32(s: str) -> int:
+    """Rust's str::parse::<i32> on a trimmed field: optional sign, digits, 32-bit range."""
+    t = s.strip()
+    body = t[1:] if t[:1] in "+-" else t
+    if not body or not body.isascii() or not body.isdigit():
+        raise ValueError("invalid digit found in string: %r" % t)
+    v = int(t)
+    if not -(1 << 31) <= v < (1 << 31):
+        raise ValueError("number too large to fit in target type: %r" % t)
+    return v
+
 
 @dataclass
 class Fusion:
-    """src/core/fusion.rs:14-16"""
+    """src/core/fusion.rs:12-107"""
     m_gene: Gene
 
     def is_reversed(self) -> bool:
         return self.m_gene.is_reversed()
+
+    def pos2str(self, pos: int) -> str:
+        return self.m_gene.pos2str(pos)
+
+    @staticmethod
+    def parse_csv_text(text: str) -> List["Fusion"]:
+        """fusion.rs:22-86 on the file's text: a ">NAME,chr:start-end" line opens a gene, the
+        "id,start,end" lines after it are its exons; "#" lines, lines with fewer than two fields
+        and exon lines with fewer than three are skipped; a gene is kept when it is valid."""
+        fusions: List[Fusion] = []
+        working = Gene()
+        for raw in text.split("\n"):
+            line = raw.strip()
+            splitted = line.split(",")
+            if len(splitted) < 2 or splitted[0].startswith("#"):
+                continue
+            if splitted[0].startswith(">"):
+                if working.valid():
+                    fusions.append(Fusion(working))
+                working = Gene.parse(line)
+                continue
+            if len(splitted) < 3:
+                continue
+            working.add_exon(_parse_i32(splitted[0]), _parse_i32(splitted[1]), _parse_i32(splitted[2]))
+        if working.valid():
+            fusions.append(Fusion(working))
+        return fusions
+
+    @staticmethod
+    def parse_csv(filename: str) -> List["Fusion"]:
+        with open(filename, "r", encoding="utf-8", newline="") as f:
+            return Fusion.parse_csv_text(f.read())
+
+
+class FastaReader:
+    """src/core/fasta_reader.rs:25-200: ``read_all`` fills ``m_all_contigs`` (name -> sequence).
+    A record runs from one '>' to the next; its name is the text up to the first newline or
+    blank; of the rest only letters, '-' and '*' are kept (newlines and everything else are
+    dropped), upper-cased when ``force_upper_case``.  ``.gz`` files are gunzipped."""
+
+    def __init__(self, fasta_file: str, force_upper_case: bool = True):
+        import gzip
+        import os
+        if os.path.isdir(fasta_file):
+            raise IsADirectoryError("There is a problem with the provided fasta file: '%s' is a directory NOT a file..."
+                                    % fasta_file)
+        self.m_fasta_file = str(fasta_file)
+        self.m_force_upper_case = force_upper_case
+        opener = gzip.open if self.m_fasta_file.endswith(".gz") else open
+        with opener(self.m_fasta_file, "rb") as f:
+            self._data = f.read()
+        if not self._data:
+            raise ValueError("empty fasta file: %s" % fasta_file)
+        self.m_all_contigs: Dict[str, bytes] = {}
+
+    def read_all(self) -> None:
+        keep = bytes(b for b in range(256) if chr(b).isalpha() and b < 128 or b in b"-*")
+        drop = bytes(set(range(256)) - set(keep))
+        first = self._data.find(b">")          # what precedes the first '>' is skipped (:66-74)
+        body = self._data[first + 1:] if first >= 0 else b""
+        records = body.split(b">")
+        if records and records[-1] == b"":       # nothing after the last '>': read_until returns 0 bytes there
+            records.pop()
+        for rec in records:                      # read_until(b'>') per record (:125-141)
+            cut = len(rec)
+            for d in (b"\n", b" "):
+                k = rec.find(d)
+                if 0 <= k < cut:
+                    cut = k
+            name = rec[:cut].decode("latin-1")
+            seq = rec[cut + 1:].translate(None, drop)   # the delimiter itself is consumed (:144-149)
+            if self.m_force_upper_case:
+                seq = seq.upper()
+            self.m_all_contigs[name] = seq
 
 
 def _as_bytes(s: BytesLike) -> bytes:

@@ -298,3 +298,75 @@ def match_sort(matches):
     out = sorted(matches, key=lambda m: m[2], reverse=True)          # name descending (stable)
     out = sorted(out, key=lambda m: m[1])                             # length ascending
     return sorted(out, key=lambda m: m[0], reverse=True)              # read_break descending
+
+
+# ---- the inputs of make_index: the fusion CSV (fusion.rs:22-86, gene.rs:43-105, :131-212) and the
+# FASTA reference (fasta_reader.rs:117-200), written from their description.  Pinned by the
+# reference's own tests: fusion.rs:112-150 (four pos2str strings on testdata/fusions.csv) and
+# fasta_reader.rs:233-258 (the two contigs of testdata/tinyref.fa.gz).
+
+import re as _re
+
+_GENE_LINE = _re.compile(r"^>(?P<name>[^,]*),(?P<chr>[^:,]*):(?P<a>[^-,:]*)-(?P<b>[^-,:]*)")
+
+
+def csv_genes(text: str):
+    """[(name, chr, start, end, [(id, start, end)...], reversed)]"""
+    genes, cur = [], None
+
+    def flush():
+        if cur is not None and cur[0] != "invalid" and cur[2] != 0 and cur[3] != 0:
+            ex = cur[4]
+            genes.append((cur[0], cur[1], cur[2], cur[3], list(ex), len(ex) > 1 and ex[0][1] > ex[1][1]))
+
+    for raw in text.splitlines():
+        line = raw.strip()
+        f = line.split(",")
+        if len(f) < 2 or f[0].startswith("#"):
+            continue
+        if f[0].startswith(">"):
+            flush()
+            m = _GENE_LINE.match(line)
+            cur = [m.group("name").strip(), m.group("chr").strip(), int(m.group("a")), int(m.group("b")), []] if m \
+                else ["invalid", "invalid", 0, 0, []]
+        elif len(f) >= 3 and cur is not None:
+            cur[4].append((int(f[0]), int(f[1]), int(f[2])))
+    flush()
+    return genes
+
+
+def gene_pos2str(gene, pos: int) -> str:
+    name, chr_, start, _end, exons, rev = gene
+    pp = abs(pos) + start
+    label = ""
+    for i, (eid, es, ee) in enumerate(exons):
+        if es <= pp <= ee:
+            label = "exon:%d|" % eid
+            break
+        if i > 0:
+            ps, pe = exons[i - 1][1], exons[i - 1][2]
+            if (rev and ee < pp < ps) or (not rev and pe < pp < es):
+                label = "intron:%d|" % (eid - 1)
+                break
+    return "%s:%s%s%s:%d" % (name, label, "+" if pos >= 0 else "-", chr_, pp)
+
+
+def fasta_contigs(data: bytes, upper: bool = True):
+    out = {}
+    i = data.find(b">")
+    if i < 0:
+        return out
+    pos = i + 1
+    n = len(data)
+    while pos < n:
+        j = data.find(b">", pos)
+        rec = data[pos:] if j < 0 else data[pos:j]
+        k = 0
+        while k < len(rec) and rec[k] not in (10, 32):
+            k += 1
+        seq = bytes(b for b in rec[k + 1:] if 65 <= b <= 90 or 97 <= b <= 122 or b in (45, 42))
+        out[rec[:k].decode("latin-1")] = seq.upper() if upper else seq
+        if j < 0:
+            break
+        pos = j + 1
+    return out

@@ -1,0 +1,141 @@
+"""The inputs of Indexer::make_index — Fusion::parse_csv / Gene (fusion.rs:22-86, gene.rs) and
+FastaReader::read_all (fasta_reader.rs:117-200) — in the host-side mirror, pinned by the
+reference's own tests: the four pos2str strings of fusion.rs:112-150 on testdata/fusions.csv
+and the two contigs of fasta_reader.rs:233-258 on testdata/tinyref.fa(.gz) (the files are
+kept as data under tests/golden/)."""
+import os
+
+import pytest
+
+from oracle import indexer_model as M
+
+HERE = os.path.dirname(__file__)
+CSV = os.path.join(HERE, "golden", "fusions.csv")
+FA = os.path.join(HERE, "golden", "tinyref.fa")
+FAGZ = os.path.join(HERE, "golden", "tinyref.fa.gz")
+
+CONTIG1 = b"GATCACAGGTCTATCACCCTATTAATTGGTATTTTCGTCTGGGGGGTGTGGAGCCGGAGCACCCTATGTCGCAGT"
+CONTIG2 = b"GTCTGCACAGCCGCTTTCCACACAGAACCCCCCCCTCCCCCCGCTTCTGGCAAACCCCAAAAACAAAGAACCCTA"
+
+
+def test_parse_csv_reference_vectors():
+    from genefuserust_amd.indexer import Fusion
+    fusions = Fusion.parse_csv(CSV)
+    by_name = {f.m_gene.m_name: f for f in fusions}
+    assert [f.m_gene.m_name for f in fusions] == ["ALK", "ROS1", "RET", "EML4"]
+    # fusion.rs:121-141
+    assert by_name["ALK"].pos2str(-30582) == "ALK:exon:20|-chr2:29446222"
+    assert by_name["ALK"].pos2str(31060) == "ALK:intron:19|+chr2:29446700"
+    assert by_name["EML4"].pos2str(95365) == "EML4:exon:6|+chr2:42491855"
+    assert by_name["EML4"].pos2str(95346) == "EML4:intron:5|+chr2:42491836"
+    assert by_name["ALK"].is_reversed() and not by_name["EML4"].is_reversed()
+    # the independent model agrees on every gene and on a sweep of positions
+    text = open(CSV).read()
+    model = M.csv_genes(text)
+    assert [(f.m_gene.m_name, f.m_gene.m_chr, f.m_gene.m_start, f.m_gene.m_end, f.m_gene.m_reversed,
+             [(e.id, e.start, e.end) for e in f.m_gene.m_exons]) for f in fusions] == \
+        [(g[0], g[1], g[2], g[3], g[5], g[4]) for g in model]
+    for f, g in zip(fusions, model):
+        span = f.m_gene.m_end - f.m_gene.m_start
+        for pos in list(range(-span, span, max(1, span // 400))) + [0, 1, -1]:
+            assert f.pos2str(pos) == M.gene_pos2str(g, pos)
+            assert f.m_gene.gene_pos_2_chr_pos(pos) == (abs(pos) + f.m_gene.m_start) * (-1 if pos < 0 else 1)
+
+
+def test_parse_csv_edges():
+    from genefuserust_amd.indexer import Fusion
+    text = "#comment,line\n\n>G1, chr9:100-900\n1,100,200\r\n2,300,400\nnot-a-line\n>BAD,nocolon\n5,1,2\n" \
+           ">G2,chrX:5000-1000, extra\n3,900,950\n2,700,800\n1,,\n"
+    with pytest.raises(ValueError):
+        Fusion.parse_csv_text(text)           # "1,," : an exon line whose numbers do not parse is an error
+    fusions = Fusion.parse_csv_text(text.replace("1,,\n", ""))
+    assert [(f.m_gene.m_name, f.m_gene.m_chr, f.m_gene.m_start, f.m_gene.m_end, f.m_gene.m_reversed) for f in fusions] == \
+        [("G1", "chr9", 100, 900, False), ("G2", "chrX", 5000, 1000, True)]
+    # the exons after the invalid ">BAD" line belong to the invalid gene, which is dropped
+    assert [(e.id, e.start, e.end) for e in fusions[0].m_gene.m_exons] == [(1, 100, 200), (2, 300, 400)]
+    assert [(g[0], g[5]) for g in M.csv_genes(text.replace("1,,\n", ""))] == [("G1", False), ("G2", True)]
+    assert fusions[1].m_gene.get_exon_intron(-(950 - 5000)) in ((None, None), (True, 3))
+
+
+def test_fasta_reader_reference_vectors():
+    from genefuserust_amd.indexer import FastaReader
+    for path in (FAGZ, FA):
+        r = FastaReader(path, True)
+        r.read_all()
+        assert r.m_all_contigs["contig1"] == CONTIG1 and r.m_all_contigs["contig2"] == CONTIG2  # fasta_reader.rs:237-238
+        assert r.m_all_contigs == M.fasta_contigs(r._data, True)
+
+
+def test_fasta_reader_edges(tmp_path):
+    from genefuserust_amd.indexer import FastaReader
+    cases = [b">a\nACGT\nacgt\n>b desc ription\nNN-*\n12\n>c\n", b"junk>x\nAC>y\nGT>", b">", b">only", b">>a\nA\n"]
+    for k, data in enumerate(cases):
+        p = tmp_path / ("t%d.fa" % k)
+        p.write_bytes(data)
+        for upper in (True, False):
+            r = FastaReader(str(p), upper)
+            r.read_all()
+            assert r.m_all_contigs == M.fasta_contigs(data, upper), (data, upper)
+    r = FastaReader(str(tmp_path / "t0.fa"), True)
+    r.read_all()
+    # the description after a blank is not part of the name — and, as in the reference, its
+    # letters end up in front of the sequence
+    assert r.m_all_contigs == {"a": b"ACGTACGT", "b": b"DESCRIPTIONNN-*", "c": b""}
+    (tmp_path / "e.fa").write_bytes(b"")
+    with pytest.raises(ValueError):
+        FastaReader(str(tmp_path / "e.fa"), True)
+
+
+def test_config0_gene_slices_resolve_to_nothing():
+    """BASELINE configs[0]: testdata/fusions.csv names chr2/chr10 genes, testdata/tinyref.fa has
+    contig1/contig2 only: every gene is unresolved (indexer.rs:137-150) and indexes nothing."""
+    from genefuserust_amd.indexer import FastaReader, Fusion, resolve_gene_slice
+    r = FastaReader(FA, True)
+    r.read_all()
+    fusions = Fusion.parse_csv(CSV)
+    assert len(fusions) >= 2 and all(resolve_gene_slice(r.m_all_contigs, f.m_gene) is None for f in fusions)
+
+
+@pytest.mark.gpu
+def test_config0_files_end_to_end(gpu_device):
+    """BASELINE configs[0] on the device: testdata R1.fq / R2.fq + tinyref.fa + fusions.csv.
+    No gene resolves, the index is empty (zero keys), every pair maps to nothing — and the
+    same plumbing with a reference that does hold the genes gives the answers of an index
+    built from the slices directly."""
+    import numpy as np
+    import torch
+    from genefuserust_amd import Indexer
+    from genefuserust_amd.fastq import FastqReaderPair
+    from genefuserust_amd.indexer import FastaReader, Fusion, Gene
+    from genefuserust_amd.read_pair import fast_merge_device
+    from tests.helpers import rand_seq
+    g = os.path.join(HERE, "golden")
+    ref = FastaReader(FA, True)
+    ref.read_all()
+    fusions = Fusion.parse_csv(CSV)
+    ix = Indexer(ref.m_all_contigs, fusions)
+    ix.make_index()
+    assert ix.info()["n_keys"] == 0 and ix.m_fusion_seq == [""] * len(fusions)
+    (l, _), (r, _) = FastqReaderPair.from_paths(os.path.join(g, "R1.fq"), os.path.join(g, "R2.fq")).read_all_device(ix)
+    assert l.n_records == r.n_records == 3
+    for b in (l, r):
+        counts, _ = ix.map_reads_device(b.bases, b.offsets, b.max_read_len())
+        assert int(counts.sum()) == 0
+    bases, quals, off, diff = fast_merge_device(ix, l.bases, l.quals, l.offsets, r.bases, r.quals, r.offsets, 151)
+    counts, _ = ix.map_reads_device(bases, off, 320)
+    torch.cuda.synchronize()
+    assert int(counts.sum()) == 0
+    ix.close()
+    # a reference that holds the genes: "chr"-prefix fallbacks of indexer.rs:137-152 included
+    rng = np.random.default_rng(8)
+    contigs = {"chr7": rand_seq(rng, 6000), "12": rand_seq(rng, 5000)}
+    genes = [Fusion(Gene("GA", "7", 500, 3500)), Fusion(Gene("GB", "chr12", 1000, 4000)), Fusion(Gene("GC", "chr3", 1, 2))]
+    a = Indexer(contigs, genes)
+    a.make_index()
+    b = Indexer.from_gene_slices([contigs["chr7"][500:3500], contigs["12"][1000:4000], None])
+    b.make_index()
+    assert a.info()["n_keys"] == b.info()["n_keys"] > 5000 and a.m_fusion_seq[2] == ""
+    read = contigs["chr7"][1000:1075] + contigs["12"][2000:2075]
+    assert a.map_read(read) == b.map_read(read) and len(a.map_read(read)) == 2
+    a.close()
+    b.close()
