@@ -10,7 +10,10 @@
 #pragma once
 
 #include <cstdint>
+#include <cctype>
+#include <fstream>
 #include <map>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -31,17 +34,160 @@ struct SeqMatch {  // src/core/indexer.rs:41-45
   GenePos start_gp;
 };
 
-struct Gene {  // fields of src/core/gene.rs:16-23 read by the Indexer
-  std::string m_name, m_chr;
-  int32_t m_start = 0, m_end = 0;
-  bool m_reversed = false;
-  bool is_reversed() const { return m_reversed; }
+struct Exon {  // src/core/gene.rs:9-13
+  int32_t id = 0, start = 0, end = 0;
 };
 
-struct Fusion {  // src/core/fusion.rs:14-16
+struct Gene {  // src/core/gene.rs:16-229
+  std::string m_name = "invalid", m_chr = "invalid";
+  int32_t m_start = 0, m_end = 0;
+  bool m_reversed = false;
+  std::vector<Exon> m_exons;
+
+  Gene() = default;
+  Gene(std::string name, std::string chr, int32_t start, int32_t end, bool reversed = false)
+      : m_name(std::move(name)), m_chr(std::move(chr)), m_start(start), m_end(end), m_reversed(reversed) {}
+
+  bool is_reversed() const { return m_reversed; }
+  bool valid() const { return m_name != "invalid" && m_start != 0 && m_end != 0; }  // :39-41
+
+  void add_exon(int32_t id, int32_t start, int32_t end) {  // :90-105
+    m_exons.push_back(Exon{id, start, end});
+    if (m_exons.size() > 1 && m_exons[0].start > m_exons[1].start) m_reversed = true;
+  }
+
+  // :131-169, e.g. "ALK:exon:20|-chr2:29446222"
+  std::string pos2str(int32_t pos) const {
+    const int32_t pp = (pos < 0 ? -pos : pos) + m_start;
+    std::string ss = m_name + ":";
+    for (size_t i = 0; i < m_exons.size(); ++i) {
+      const Exon& e = m_exons[i];
+      if (pp >= e.start && pp <= e.end) {
+        ss += "exon:" + std::to_string(e.id) + "|";
+        break;
+      }
+      if (i > 0) {
+        const Exon& p = m_exons[i - 1];
+        if (m_reversed ? (e.end < pp && pp < p.start) : (p.end < pp && pp < e.start)) {
+          ss += "intron:" + std::to_string(e.id - 1) + "|";
+          break;
+        }
+      }
+    }
+    ss += pos >= 0 ? "+" : "-";
+    return ss + m_chr + ":" + std::to_string(pp);
+  }
+
+  int32_t gene_pos_2_chr_pos(int32_t genepos) const {  // :205-212
+    const int32_t chrpos = (genepos < 0 ? -genepos : genepos) + m_start;
+    return genepos < 0 ? -chrpos : chrpos;
+  }
+};
+
+namespace detail {
+inline std::string trim(const std::string& s) {
+  size_t a = 0, b = s.size();
+  while (a < b && isspace((unsigned char)s[a])) ++a;
+  while (b > a && isspace((unsigned char)s[b - 1])) --b;
+  return s.substr(a, b - a);
+}
+inline std::vector<std::string> split(const std::string& s, char d) {
+  std::vector<std::string> out;
+  size_t a = 0;
+  for (;;) {
+    const size_t b = s.find(d, a);
+    out.push_back(s.substr(a, b == std::string::npos ? std::string::npos : b - a));
+    if (b == std::string::npos) break;
+    a = b + 1;
+  }
+  return out;
+}
+// Rust's str::parse::<i32> on a trimmed field: optional sign, digits, 32-bit range; throws otherwise
+inline int32_t parse_i32(const std::string& field) {
+  const std::string t = trim(field);
+  size_t k = (!t.empty() && (t[0] == '+' || t[0] == '-')) ? 1 : 0;
+  if (k == t.size()) throw std::runtime_error("invalid digit found in string: '" + t + "'");
+  long long v = 0;
+  for (size_t i = k; i < t.size(); ++i) {
+    if (t[i] < '0' || t[i] > '9') throw std::runtime_error("invalid digit found in string: '" + t + "'");
+    v = v * 10 + (t[i] - '0');
+    if (v > 2147483648LL) throw std::runtime_error("number too large to fit in target type: '" + t + "'");
+  }
+  if (t[0] == '-') v = -v;
+  if (v > 2147483647LL) throw std::runtime_error("number too large to fit in target type: '" + t + "'");
+  return (int32_t)v;
+}
+}  // namespace detail
+
+inline Gene gene_parse(const std::string& line_str) {  // Gene::parse, gene.rs:43-88
+  const auto splitted = detail::split(line_str, ',');
+  if (splitted.size() < 2) return Gene();
+  const std::string name = detail::trim(splitted[0].substr(splitted[0].empty() ? 0 : 1));
+  const auto chr_pos = detail::split(splitted[1], ':');
+  if (chr_pos.size() < 2) return Gene();
+  const auto range = detail::split(chr_pos[1], '-');
+  if (range.size() < 2) return Gene();
+  return Gene(name, detail::trim(chr_pos[0]), detail::parse_i32(range[0]), detail::parse_i32(range[1]));
+}
+
+struct Fusion {  // src/core/fusion.rs:12-107
   Gene m_gene;
   bool is_reversed() const { return m_gene.is_reversed(); }
+  std::string pos2str(int32_t pos) const { return m_gene.pos2str(pos); }
+
+  // Fusion::parse_csv (:22-86) on the file's text
+  static std::vector<Fusion> parse_csv_text(const std::string& text) {
+    std::vector<Fusion> fusions;
+    Gene working;
+    for (const std::string& raw : detail::split(text, '\n')) {
+      const std::string line = detail::trim(raw);
+      const auto splitted = detail::split(line, ',');
+      if (splitted.size() < 2 || (!splitted[0].empty() && splitted[0][0] == '#')) continue;
+      if (!splitted[0].empty() && splitted[0][0] == '>') {
+        if (working.valid()) fusions.push_back(Fusion{working});
+        working = gene_parse(line);
+        continue;
+      }
+      if (splitted.size() < 3) continue;
+      working.add_exon(detail::parse_i32(splitted[0]), detail::parse_i32(splitted[1]), detail::parse_i32(splitted[2]));
+    }
+    if (working.valid()) fusions.push_back(Fusion{working});
+    return fusions;
+  }
+  static std::vector<Fusion> parse_csv(const std::string& filename) {
+    std::ifstream f(filename, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + filename);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return parse_csv_text(ss.str());
+  }
 };
+
+// FastaReader::read_all (fasta_reader.rs:117-200) on the (already gunzipped) bytes of a file:
+// name -> sequence.  A record runs from one '>' to the next; its name ends at the first
+// newline or blank; of the rest only letters, '-' and '*' are kept, upper-cased on request.
+inline std::map<std::string, std::string> fasta_read_all(const std::string& data, bool force_upper_case = true) {
+  std::map<std::string, std::string> contigs;
+  size_t pos = data.find('>');
+  if (pos == std::string::npos) return contigs;
+  ++pos;
+  while (pos < data.size()) {
+    const size_t next = data.find('>', pos);
+    const std::string rec = data.substr(pos, next == std::string::npos ? std::string::npos : next - pos);
+    size_t k = 0;
+    while (k < rec.size() && rec[k] != '\n' && rec[k] != ' ') ++k;
+    std::string seq;
+    for (size_t i = k + 1; i < rec.size(); ++i) {
+      const unsigned char b = (unsigned char)rec[i];
+      if ((b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '-' || b == '*')
+        seq.push_back(force_upper_case && b >= 'a' && b <= 'z' ? (char)(b - 32) : (char)b);
+    }
+    contigs[rec.substr(0, k)] = seq;
+    if (next == std::string::npos) break;
+    pos = next + 1;
+  }
+  return contigs;
+}
 
 class Indexer {
  public:

@@ -139,3 +139,14 @@ def test_config0_files_end_to_end(gpu_device):
     assert a.map_read(read) == b.map_read(read) and len(a.map_read(read)) == 2
     a.close()
     b.close()
+
+
+def test_cpp_mirror_of_the_inputs(tmp_path):
+    """include/gf_indexer.hpp: the same parsers in the C++ mirror, same reference vectors (host only)."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "test_inputs")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"),
+                    os.path.join(HERE, "cpp", "test_inputs.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe, CSV, FA], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
