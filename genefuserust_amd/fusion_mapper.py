@@ -41,6 +41,7 @@ class ReadMatch:
     m_right_distance: int
     m_reversed: bool = False
     m_name: bytes = b""   # SequenceRead.m_name: the last key of the sort order (read_match.rs:226)
+    m_source: str = ""    # which read of a pair it was found on: "merged", "r1" or "r2" (scan_pair_end)
 
 
 def edit_distance(a: BytesLike, b: BytesLike) -> int:

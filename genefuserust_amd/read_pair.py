@@ -113,16 +113,16 @@ def scan_pair_end(mapper: FusionMapper, pairs: Sequence[SequenceReadPair]) -> Li
     complement of a merged read has not (:465-468)."""
     merged = fast_merge_batch(mapper.m_indexer, pairs)
     cands: List[bytes] = []
-    owner: List[Tuple[int, bool]] = []  # (pair, is_merged)
+    owner: List[Tuple[int, str]] = []  # (pair, "merged" | "r1" | "r2")
     for p, (pair, m) in enumerate(zip(pairs, merged)):
         if m is not None:
             cands.append(m.seq)
-            owner.append((p, True))
+            owner.append((p, "merged"))
         else:
             cands.append(pair.m_left[0])
-            owner.append((p, False))
+            owner.append((p, "r1"))
             cands.append(pair.m_right[0])
-            owner.append((p, False))
+            owner.append((p, "r2"))
     first = mapper.map_reads(cands)
     found: List[Optional[ReadMatch]] = [m for m, _ in first]
     retry = [i for i, (m, mapable) in enumerate(first) if m is None and mapable]
@@ -130,11 +130,12 @@ def scan_pair_end(mapper: FusionMapper, pairs: Sequence[SequenceReadPair]) -> Li
         second = mapper.map_reads([reverse_complement(cands[i]) for i in retry])
         for i, (m, _) in zip(retry, second):
             if m is not None:
-                if not owner[i][1]:
+                if owner[i][1] != "merged":
                     m.m_reversed = True
                 found[i] = m
     out: List[List[ReadMatch]] = [[] for _ in pairs]
     for i, m in enumerate(found):
         if m is not None:
+            m.m_source = owner[i][1]
             out[owner[i][0]].append(m)
     return out

@@ -1,0 +1,52 @@
+"""The front half of ``PairEndScanner::scan`` (src/core/pescanner.rs:78-518) from the reference's
+own file formats: FASTA + fusion CSV -> index; R1/R2 FASTQ -> records -> per-pair policy
+(merge, map, reverse-complement retries) -> ``ReadMatch`` lists, filtered and sorted the way
+``FusionMapper::filter_matches`` (without ``remove_alignables``) and ``sort_matches`` do.
+
+Glue only: every step is one of the mirrors in this package, and all compute goes through
+libgfmatch.so.  What the reference does after this point (clustering, qualification,
+reports) is not here.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+from .fastq import FastqReaderPair, record_lines
+from .fusion_mapper import FusionMapper, ReadMatch
+from .indexer import FastaReader, Fusion, Indexer
+from .read_pair import SequenceReadPair, scan_pair_end
+
+
+def scan_pair_end_files(ref_file: str, fusion_csv: str, read1_file: str, read2_file: str, device: int = -1,
+                        deletion_threshold: int = 50) -> Tuple[List[ReadMatch], dict]:
+    """Returns (matches kept, in ``sort_matches`` order; counters).  Each match carries the name
+    of the read it was found on (the R1 name for merged reads, like read.rs:372 without the
+    " merged_diff_N" suffix the reference appends)."""
+    ref = FastaReader(ref_file, True)
+    ref.read_all()
+    fusions = Fusion.parse_csv(fusion_csv)
+    ix = Indexer(ref.m_all_contigs, fusions, device)
+    ix.make_index()
+    try:
+        (l, ltext), (r, rtext) = FastqReaderPair.from_paths(read1_file, read2_file).read_all_device(ix)
+        lo, ro = l.offsets.cpu().numpy(), r.offsets.cpu().numpy()
+        lb, lq = l.bases.cpu().numpy().tobytes(), l.quals.cpu().numpy().tobytes()
+        rb, rq = r.bases.cpu().numpy().tobytes(), r.quals.cpu().numpy().tobytes()
+        pairs = [SequenceReadPair((lb[lo[i]:lo[i + 1]], lq[lo[i]:lo[i + 1]]), (rb[ro[i]:ro[i + 1]], rq[ro[i]:ro[i + 1]]))
+                 for i in range(l.n_records)]
+        mapper = FusionMapper(ix)
+        per_pair = scan_pair_end(mapper, pairs)
+        found: List[ReadMatch] = []
+        for i, ms in enumerate(per_pair):
+            if not ms:
+                continue
+            name1 = record_lines(l, ltext, i)[0]
+            name2 = record_lines(r, rtext, i)[0]
+            for m in ms:  # a match on R2 (or its reverse complement) carries R2's name; anything else R1's
+                m.m_name = name2 if m.m_source == "r2" else name1
+                found.append(m)
+        kept, removed = mapper.filter_matches(found, deletion_threshold)
+        counters = {"pairs": l.n_records, "matches_before_filtering": len(found), **removed}
+        return FusionMapper.sort_matches(kept), counters
+    finally:
+        ix.close()

@@ -150,3 +150,57 @@ def test_cpp_mirror_of_the_inputs(tmp_path):
                     os.path.join(HERE, "cpp", "test_inputs.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe, CSV, FA], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_scan_pair_end_files(gpu_device, tmp_path):
+    """Files in, sorted ReadMatch list out: a FASTA with two genes, a fusion CSV, and paired FASTQ
+    files cut from planted fusions (plus background).  The matches must name the planted pairs,
+    sit at the planted breakpoints, and come out in the sort_matches order."""
+    import gzip
+    import numpy as np
+    from genefuserust_amd.scan import scan_pair_end_files
+    from tests.helpers import rand_seq, rc
+    rng = np.random.default_rng(12)
+    chr1, chr2 = rand_seq(rng, 9000), rand_seq(rng, 8000)
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(b">chr1 test\n" + b"\n".join(chr1[i:i + 60] for i in range(0, len(chr1), 60)) +
+                   b"\n>chr2\n" + chr2.lower() + b"\n")
+    csv = tmp_path / "f.csv"
+    csv.write_text(">GA,chr1:1000-7000\n1,1000,3000\n2,4000,7000\n\n>GB,chr2:500-6500\n1,500,2500\n2,3500,6500\n")
+    # "chr1 test": the description's letters are prepended to the sequence by the reference's reader
+    shift = len(b"TEST")
+    ga = (b"TEST" + chr1)[1000:7000]
+    gb = chr2.upper()[500:6500]
+    l_txt, r_txt, planted = [], [], {}
+    for k in range(60):
+        if k % 3 == 0:
+            p, q = int(rng.integers(400, 5500)), int(rng.integers(400, 5500))
+            frag = ga[p - 140:p] + gb[q:q + 140]
+            planted[b"@pair%d/1" % k] = (p - 1, q)
+        else:
+            frag = rand_seq(rng, 280)
+        flen = int(rng.integers(200, 281))
+        lo = (280 - flen) // 2
+        f = frag[lo:lo + flen]
+        s1, s2 = f[:150], rc(f)[:150]
+        l_txt += [b"@pair%d/1" % k, s1, b"+", b"F" * len(s1)]
+        r_txt += [b"@pair%d/2" % k, s2, b"+", b"F" * len(s2)]
+    r1, r2 = tmp_path / "R1.fq", tmp_path / "R2.fq.gz"
+    r1.write_bytes(b"\n".join(l_txt) + b"\n")
+    with gzip.open(r2, "wb") as f:
+        f.write(b"\n".join(r_txt) + b"\n")
+    kept, counters = scan_pair_end_files(str(fa), str(csv), str(r1), str(r2))
+    assert counters["pairs"] == 60 and shift == 4
+    names = {m.m_name for m in kept}
+    assert names <= set(planted) and len(names) >= 15
+    for m in kept:
+        p_last, q_first = planted[m.m_name]
+        left, right = (m.m_left_gp, m.m_right_gp)
+        assert {left.contig, right.contig} == {0, 1}
+        a = left if left.contig == 0 else right
+        b = right if left.contig == 0 else left
+        # the breakpoint may slide by a few bases where the flanks agree by chance
+        assert abs(abs(a.position) - p_last) <= 4 and abs(abs(b.position) - q_first) <= 4
+    order = [(m.m_read_break, len(m.m_read), m.m_name) for m in kept]
+    assert order == sorted(order, key=lambda t: (-t[0], t[1], tuple(-c for c in t[2])))
