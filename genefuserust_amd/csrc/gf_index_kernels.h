@@ -229,8 +229,12 @@ __global__ void gf_k_build_bloom(const uint64_t* slots, uint64_t nslots, uint32_
     if (((uint32_t)v & GF_VAL_LOW) == 0) continue;
     const uint32_t key = (uint32_t)(v >> 32);
     const uint32_t ha = GF_BLOOM_HASH((key >> 4)), hb = GF_BLOOM_HASH((key & 0x0FFFFFFFu));
-    atomicOr(bloom + GF_BLOOM_WORD(ha, nwords), GF_BLOOM_BITS(ha));
-    atomicOr(bloom + GF_BLOOM_WORD(hb, nwords), GF_BLOOM_BITS(hb));
+    // neighbouring keys share their 14-mers, so most bit pairs are set already: look before the atomic
+    uint32_t* wa = bloom + GF_BLOOM_WORD(ha, nwords);
+    uint32_t* wb = bloom + GF_BLOOM_WORD(hb, nwords);
+    const uint32_t ba = GF_BLOOM_BITS(ha), bb = GF_BLOOM_BITS(hb);
+    if ((__builtin_nontemporal_load(wa) & ba) != ba) atomicOr(wa, ba);
+    if ((__builtin_nontemporal_load(wb) & bb) != bb) atomicOr(wb, bb);
   }
 }
 
@@ -249,27 +253,54 @@ __global__ void gf_k_classify_count(const uint64_t* slots, uint64_t nslots,
     else if (c <= GF_DUP_THRESHOLD) { dk += 1; ds += c; }
     else high += 1;
   }
+  // one atomic per block and statistic (one per wave serialised ~100 K atomics on six addresses)
+  __shared__ unsigned long long s_part[6][4];
   unsigned long long v[6] = {sites, keys, uniq, dk, high, ds};
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     unsigned long long x = v[k];
     for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
-    if ((threadIdx.x & 63) == 0 && x) atomicAdd(stats + k, x);
+    if ((threadIdx.x & 63) == 0) s_part[k][(threadIdx.x >> 6) & 3] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    unsigned long long x = 0;
+    for (unsigned int w = 0; w < (blockDim.x + 63) / 64 && w < 4; ++w) x += s_part[threadIdx.x][w];
+    if (x) atomicAdd(stats + threadIdx.x, x);
   }
 }
 
 __global__ void gf_k_classify_assign(uint64_t* slots, uint64_t nslots, unsigned long long* stats) {
-  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots;
-       s += (uint64_t)gridDim.x * blockDim.x) {
-    uint32_t* valp = (uint32_t*)(slots + s);
-    uint32_t val = *valp;
-    uint32_t c = val & GF_VAL_LOW;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t rounds = (nslots + stride - 1) / stride;  // whole waves stay in the loop for the shuffles
+  for (uint64_t it = 0; it < rounds; ++it) {
+    const uint64_t s = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t val = 0, c = 0;
+    uint32_t* valp = nullptr;
+    if (s < nslots) {
+      valp = (uint32_t*)(slots + s);
+      val = *valp;
+      c = val & GF_VAL_LOW;
+    }
+    // room in dupes[] for the 2..5-fold keys of this wave: one atomic per wave, not per key
+    const uint32_t want = (c >= 2 && c <= GF_DUP_THRESHOLD) ? c : 0u;
+    uint32_t incl = want;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o);
+      if ((int)(threadIdx.x & 63) >= o) incl += y;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    unsigned long long base = 0;
+    if (total) {
+      if ((threadIdx.x & 63) == 0) base = atomicAdd(stats + 6, (unsigned long long)total);
+      base = __shfl(base, 0);
+    }
     if (!c) continue;
     uint32_t nv;
     if (c == 1) {
       nv = GF_TYPE_UNIQUE << GF_TYPE_SHIFT;
     } else if (c <= GF_DUP_THRESHOLD) {
-      uint32_t start = (uint32_t)atomicAdd(stats + 6, (unsigned long long)c);
+      const uint32_t start = (uint32_t)base + incl - want;
       nv = (GF_TYPE_DUPES << GF_TYPE_SHIFT) | (c << GF_DUPE_COUNT_SHIFT) | start;
     } else {
       nv = GF_TYPE_HIGH << GF_TYPE_SHIFT;
