@@ -76,7 +76,9 @@ __device__ __forceinline__ uint64_t* gf_find_slot(uint64_t* slots, uint32_t nbuc
 }
 
 // FILL pass: store the site code of one occurrence.
-__device__ __forceinline__ void gf_fill_site(uint64_t* slots, uint32_t nbuckets, uint32_t* dupes,
+// For a key with exactly one site the site's "unique" flag in gdu is set here too (the flag
+// word of site code lin is gdu[2 * (lin >> 4) + 1], bit 2 * (lin & 15)): the slot is in hand.
+__device__ __forceinline__ void gf_fill_site(uint64_t* slots, uint32_t nbuckets, uint32_t* dupes, uint32_t* gdu,
                                              uint32_t key, uint32_t lin) {
   uint64_t* s = gf_find_slot(slots, nbuckets, key);
   if (!s) return;
@@ -86,6 +88,7 @@ __device__ __forceinline__ void gf_fill_site(uint64_t* slots, uint32_t nbuckets,
   if (type == GF_TYPE_UNIQUE) {
     // exactly one occurrence => exactly one writer
     *valp = (val & GF_VAL_OVF) | (GF_TYPE_UNIQUE << GF_TYPE_SHIFT) | (lin & GF_LIN_MASK);
+    atomicOr(gdu + 2 * (lin >> 4) + 1, 1u << (2u * (lin & 15u)));
   } else if (type == GF_TYPE_DUPES) {
     uint32_t cnt = (val >> GF_DUPE_COUNT_SHIFT) & 7u;
     uint32_t start = val & GF_DUPE_START_MASK;
@@ -100,7 +103,7 @@ __device__ __forceinline__ void gf_fill_site(uint64_t* slots, uint32_t nbuckets,
 template <int MODE>
 __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_sites(GfGenes G, uint64_t* slots,
                                                                      uint32_t nbuckets,
-                                                                     uint32_t* dupes) {
+                                                                     uint32_t* dupes, uint32_t* gdu) {
   __shared__ uint32_t s_codes[GF_TILE_BASES / 16 + 2];
   __shared__ uint32_t s_inv[GF_TILE_BASES / 32 + 2];
   const uint32_t t0 = blockIdx.x * GF_TILE_BASES;
@@ -142,19 +145,19 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_sites(GfGenes G, 
     uint32_t key = gf_window(s_codes[l >> 4], s_codes[(l >> 4) + 1], (uint32_t)l);
     if (f + GF_KMER < len) {  // forward windows 0 .. len-17 (indexer.rs:188)
       if (MODE == GF_MODE_COUNT) gf_insert_count(slots, nbuckets, key);
-      else gf_fill_site(slots, nbuckets, dupes, key, G.lin_base[lo] + f);
+      else gf_fill_site(slots, nbuckets, dupes, gdu, key, G.lin_base[lo] + f);
     }
     if (f >= 1) {  // reverse windows i = len-16-f in 0 .. len-17
       uint32_t rkey = gf_revcomp_key(key);
       if (MODE == GF_MODE_COUNT) gf_insert_count(slots, nbuckets, rkey);
-      else gf_fill_site(slots, nbuckets, dupes, rkey, G.lin_base[lo] - (f + 15u));
+      else gf_fill_site(slots, nbuckets, dupes, gdu, rkey, G.lin_base[lo] - (f + 15u));
     }
   }
 }
 
-// After FILL: publish both strands of the genes in site-code space and the per-site
-// uniqueness flags (gdu, layout: gf_table.h) used by the diagonal verification of the
-// mapping kernels.  gdu is zero-filled by the host; bits are OR-ed in.
+// Publish both strands of the genes in site-code space (gdu, layout: gf_table.h), used by the
+// diagonal verification of the mapping kernels.  gdu is zero-filled by the host; bits are
+// OR-ed in.  (The per-site uniqueness flags of gdu are set by the FILL pass.)
 __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_strands(GfGenes G, uint64_t* slots,
                                                                        uint32_t nbuckets,
                                                                        uint32_t* __restrict__ gdu) {
@@ -188,7 +191,6 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_strands(GfGenes G
       if (G.gene_off[mid] <= g) lo = mid; else hi = mid;
     }
     const uint32_t f = g - G.gene_off[lo];
-    const uint32_t len = G.gene_off[lo + 1] - G.gene_off[lo];
     const uint32_t base = G.lin_base[lo];
     // this base on both strands (invalid bases keep code 0: their windows carry no ub bit)
     const uint32_t code = (s_codes[l >> 4] >> (2 * (l & 15))) & 3u;
@@ -199,23 +201,6 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_strands(GfGenes G
       if (f >= 1) {
         const uint32_t pr = base - f;  // reverse-complement base j = len-1-f at base + 1 - len + j
         atomicOr(gdu + 2 * (pr >> 4), (code ^ 2u) << (2 * (pr & 15u)));
-      }
-    }
-    if (f + GF_KMER > len) continue;
-    if (gf_flags16(s_inv[l >> 5], s_inv[(l >> 5) + 1], (uint32_t)l)) continue;
-    const uint32_t key = gf_window(s_codes[l >> 4], s_codes[(l >> 4) + 1], (uint32_t)l);
-    if (f + GF_KMER < len) {
-      const uint64_t* s = gf_find_slot(slots, nbuckets, key);
-      if (s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) {
-        const uint32_t p = base + f;
-        atomicOr(gdu + 2 * (p >> 4) + 1, 1u << (2u * (p & 15u)));
-      }
-    }
-    if (f >= 1) {
-      const uint64_t* s = gf_find_slot(slots, nbuckets, gf_revcomp_key(key));
-      if (s && ((((uint32_t)*s) & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) {
-        const uint32_t p = base - (f + 15u);
-        atomicOr(gdu + 2 * (p >> 4) + 1, 1u << (2u * (p & 15u)));
       }
     }
   }

@@ -334,7 +334,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   unsigned long long stats[8] = {0};
   if (ntiles > 0) {
     hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_COUNT>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
-                       ix->d_slots, nbuckets, (uint32_t*)nullptr);
+                       ix->d_slots, nbuckets, (uint32_t*)nullptr, (uint32_t*)nullptr);
     GF_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(gf_k_classify_count, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
@@ -349,7 +349,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   GF_HIP(hipGetLastError());
   if (ntiles > 0) {
     hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_FILL>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
-                       ix->d_slots, nbuckets, ix->d_dupes);
+                       ix->d_slots, nbuckets, ix->d_dupes, ix->d_gdu);
     GF_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(gf_k_sort_dupes, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_dupes);
