@@ -9,6 +9,8 @@ from .indexer import (Exon, FastaReader, Fusion, Gene, GenePos, Indexer, SeqMatc
                       unpack_matches)
 from .fusion_mapper import FusionMapper, ReadMatch, edit_distance, reverse_complement  # noqa: F401
 from .read_pair import MergedRead, SequenceReadPair, fast_merge_batch, fast_merge_device, scan_pair_end  # noqa: F401
+from .fusion_result import (FusionResult, Settings, cluster_matches, group_and_sort, report_json,  # noqa: F401
+                            report_text)
 from .fastq import FastqBatch, FastqReader, FastqReaderPair, fastq_cut_device, record_lines  # noqa: F401
 
 __version__ = "0.1.0"

@@ -42,6 +42,8 @@ class ReadMatch:
     m_reversed: bool = False
     m_name: bytes = b""   # SequenceRead.m_name: the last key of the sort order (read_match.rs:226)
     m_source: str = ""    # which read of a pair it was found on: "merged", "r1" or "r2" (scan_pair_end)
+    m_quality: bytes = b""  # SequenceRead.m_quality of m_read (reversed when m_read is a reverse complement)
+    m_merge_diff: int = -1  # the N of the " merged_diff_N" name suffix when m_read is a merged pair (read.rs:372)
 
 
 def edit_distance(a: BytesLike, b: BytesLike) -> int:

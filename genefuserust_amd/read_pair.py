@@ -113,18 +113,25 @@ def scan_pair_end(mapper: FusionMapper, pairs: Sequence[SequenceReadPair]) -> Li
     complement of a merged read has not (:465-468)."""
     merged = fast_merge_batch(mapper.m_indexer, pairs)
     cands: List[bytes] = []
+    quals: List[bytes] = []
     owner: List[Tuple[int, str]] = []  # (pair, "merged" | "r1" | "r2")
     for p, (pair, m) in enumerate(zip(pairs, merged)):
         if m is not None:
             cands.append(m.seq)
+            quals.append(m.quality)
             owner.append((p, "merged"))
         else:
             cands.append(pair.m_left[0])
+            quals.append(pair.m_left[1])
             owner.append((p, "r1"))
             cands.append(pair.m_right[0])
+            quals.append(pair.m_right[1])
             owner.append((p, "r2"))
     first = mapper.map_reads(cands)
     found: List[Optional[ReadMatch]] = [m for m, _ in first]
+    for i, m in enumerate(found):
+        if m is not None:
+            m.m_quality = quals[i]
     retry = [i for i, (m, mapable) in enumerate(first) if m is None and mapable]
     if retry:
         second = mapper.map_reads([reverse_complement(cands[i]) for i in retry])
@@ -132,10 +139,13 @@ def scan_pair_end(mapper: FusionMapper, pairs: Sequence[SequenceReadPair]) -> Li
             if m is not None:
                 if owner[i][1] != "merged":
                     m.m_reversed = True
+                m.m_quality = quals[i][::-1]  # SequenceRead::reverse_complement reverses the quality (read.rs:243-261)
                 found[i] = m
     out: List[List[ReadMatch]] = [[] for _ in pairs]
     for i, m in enumerate(found):
         if m is not None:
             m.m_source = owner[i][1]
+            if m.m_source == "merged":
+                m.m_merge_diff = merged[owner[i][0]].diff
             out[owner[i][0]].append(m)
     return out

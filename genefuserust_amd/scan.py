@@ -4,8 +4,9 @@ own file formats: FASTA + fusion CSV -> index; R1/R2 FASTQ -> records -> per-pai
 ``FusionMapper::filter_matches`` (without ``remove_alignables``) and ``sort_matches`` do.
 
 Glue only: every step is one of the mirrors in this package, and all compute goes through
-libgfmatch.so.  What the reference does after this point (clustering, qualification,
-reports) is not here.
+libgfmatch.so.  ``scan_pair_end_report`` adds the back half (clustering, qualification, text and
+JSON results: SURVEY.md §8(f)-4, ``fusion_result.py``).  ``remove_alignables`` (§8(f)-3) is not
+applied: the reference's ``Matcher`` removes nothing.
 """
 from __future__ import annotations
 
@@ -13,15 +14,16 @@ from typing import List, Tuple
 
 from .fastq import FastqReaderPair, record_lines
 from .fusion_mapper import FusionMapper, ReadMatch
+from .fusion_result import FusionResult, Settings, cluster_matches, group_and_sort, report_json, report_text
 from .indexer import FastaReader, Fusion, Indexer
 from .read_pair import SequenceReadPair, scan_pair_end
 
 
 def scan_pair_end_files(ref_file: str, fusion_csv: str, read1_file: str, read2_file: str, device: int = -1,
-                        deletion_threshold: int = 50) -> Tuple[List[ReadMatch], dict]:
+                        deletion_threshold: int = 50, _keep: dict = None) -> Tuple[List[ReadMatch], dict]:
     """Returns (matches kept, in ``sort_matches`` order; counters).  Each match carries the name
-    of the read it was found on (the R1 name for merged reads, like read.rs:372 without the
-    " merged_diff_N" suffix the reference appends)."""
+    of the read it was found on (for a merged read the R1 name with the " merged_diff_N" suffix of
+    read.rs:372)."""
     ref = FastaReader(ref_file, True)
     ref.read_all()
     fusions = Fusion.parse_csv(fusion_csv)
@@ -44,9 +46,29 @@ def scan_pair_end_files(ref_file: str, fusion_csv: str, read1_file: str, read2_f
             name2 = record_lines(r, rtext, i)[0]
             for m in ms:  # a match on R2 (or its reverse complement) carries R2's name; anything else R1's
                 m.m_name = name2 if m.m_source == "r2" else name1
+                if m.m_source == "merged":
+                    m.m_name += b" merged_diff_%d" % m.m_merge_diff
                 found.append(m)
         kept, removed = mapper.filter_matches(found, deletion_threshold)
         counters = {"pairs": l.n_records, "matches_before_filtering": len(found), **removed}
+        if _keep is not None:
+            _keep.update(fusions=fusions, fusion_seq=list(ix.m_fusion_seq))
         return FusionMapper.sort_matches(kept), counters
     finally:
         ix.close()
+
+
+def scan_pair_end_report(ref_file: str, fusion_csv: str, read1_file: str, read2_file: str, device: int = -1,
+                         settings: Settings = None) -> Tuple[List[FusionResult], dict]:
+    """The whole of ``PairEndScanner::scan`` up to the reporters (pescanner.rs:78-176, :335-337):
+    files -> matches -> filter -> per-gene-pair sort -> cluster -> qualified fusions, most
+    supported first.  ``report_text`` / ``report_json`` of fusion_result.py turn the list into
+    the reference's stdout block and JSON file."""
+    settings = settings or Settings()
+    keep: dict = {}
+    kept, counters = scan_pair_end_files(ref_file, fusion_csv, read1_file, read2_file, device,
+                                         settings.deletion_threshold, keep)
+    groups = group_and_sort(kept, len(keep["fusions"]))
+    results = cluster_matches(groups, keep["fusions"], keep["fusion_seq"], settings)
+    counters["fusions"] = len(results)
+    return results, counters

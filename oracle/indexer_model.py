@@ -370,3 +370,101 @@ def fasta_contigs(data: bytes, upper: bool = True):
             break
         pos = j + 1
     return out
+
+
+# ---- clustering of the sorted matches into fusion candidates, written from
+# the description of fusion_mapper.rs:399-486 / fusion_result.rs:60-510 (first fit within 3 bp,
+# fusion point = first gap-free match else the truncated mean, reference windows either side of
+# the point, break shifted by -3..3 to the smallest 20+20-base edit distance, qualification).
+# Textbook Levenshtein and plain slicing on purpose.  A match is a dict with keys
+# seq, brk, left=(contig,pos), right=(contig,pos), gap, ld, rd.
+
+def _window(gene_seq: str, a: int, b: int) -> str:
+    """Bases a..b (inclusive, gene coordinates; negative = the reverse strand) or "" when the
+    window touches 0, changes sign or leaves the gene."""
+    if a == 0 or b == 0 or (a > 0) != (b > 0) or abs(a) >= len(gene_seq) or abs(b) >= len(gene_seq):
+        return ""
+    n = abs(b - a) + 1
+    return gene_seq[a:a + n] if a > 0 else revcomp(gene_seq[-b:-b + n])
+
+
+def _continues(s1: str, s2: str) -> bool:
+    """Do s1 and s2 read the same within a slide of 6 and a tenth of mismatches?"""
+    for off in range(-6, 7):
+        a0, b0, n = max(off, 0), max(-off, 0), len(s1) - abs(off)
+        if a0 >= len(s1) or b0 >= len(s2):
+            return True
+        if b0 + n > len(s2) or n < 0:
+            raise IndexError("window beyond the sequence")
+        if levenshtein(s1[a0:a0 + n], s2[b0:b0 + n]) <= int(n / 10):
+            return True
+    return False
+
+
+def _runs(s: str) -> int:
+    return sum(1 for a, b in zip(s, s[1:]) if a != b)
+
+
+def cluster_model(groups, genes, fusion_seq, unique_requirement: int = 2, output_deletions: bool = False,
+                  output_untranslated: bool = False):
+    """groups: lists of matches (each list sorted already); genes: csv_genes() tuples.
+    Returns the qualified candidates as dicts, most unique reads first."""
+    found = []
+    for group in groups:
+        clusters = []
+        for m in group:
+            for c in clusters:
+                if any(m["left"][0] == x["left"][0] and m["right"][0] == x["right"][0] and
+                       abs(m["left"][1] - x["left"][1]) <= 3 and abs(m["right"][1] - x["right"][1]) <= 3 for x in c):
+                    c.append(m)
+                    break
+            else:
+                clusters.append([m])
+        for c in clusters:
+            exact = [m for m in c if m["gap"] == 0]
+            if exact:
+                left, right = exact[0]["left"], exact[0]["right"]
+            else:
+                left = (c[0]["left"][0], int(sum(m["left"][1] for m in c) / len(c)))
+                right = (c[0]["right"][0], int(sum(m["right"][1] for m in c) / len(c)))
+            ll = max(m["brk"] + 1 for m in c)
+            lr = max(len(m["seq"]) - m["brk"] - 1 for m in c)
+            gl, gr = fusion_seq[left[0]], fusion_seq[right[0]]
+            lref, rref = _window(gl, left[1] - ll + 1, left[1]), _window(gr, right[1], right[1] + lr - 1)
+            lext, rext = _window(gl, left[1], left[1] + lr - 1), _window(gr, right[1] - ll + 1, right[1])
+            reads = []
+            for m in c:
+                best = None
+                for s in range(-3, 4):
+                    k = m["brk"] + s + 1
+                    a, b = m["seq"][:k], m["seq"][k:]
+                    na, nb = min(len(a), len(lref), 20), min(len(b), len(rref), 20)
+                    near = levenshtein(a[len(a) - na:], lref[len(lref) - na:]) + levenshtein(b[:nb], rref[:nb])
+                    if best is None or near < best[0]:
+                        na, nb = min(len(a), len(lref)), min(len(b), len(rref))
+                        best = (near, s, levenshtein(a[len(a) - na:], lref[len(lref) - na:]),
+                                levenshtein(b[:nb], rref[:nb]))
+                _, s, ld, rd = best
+                reads.append(dict(m, brk=m["brk"] + s, left=(m["left"][0], m["left"][1] + s),
+                                  right=(m["right"][0], m["right"][1] + s), ld=ld, rd=rd))
+            unique = 1 + sum(1 for p, q in zip(reads, reads[1:])
+                             if p["brk"] != q["brk"] or len(p["seq"]) != len(q["seq"]))
+            deletion = left[0] == right[0] and left[1] != 0 and right[1] != 0 and (left[1] > 0) == (right[1] > 0)
+            if unique < unique_requirement:
+                continue
+            if _continues(lext, rref) or _continues(lref, rext):
+                continue
+            if len(lref) <= 30 or len(rref) <= 30 or _runs(lref[-10:]) <= 2 or _runs(rref[:10]) <= 2:
+                continue
+            if deletion and not output_deletions:
+                continue
+            lfwd = (left[1] < 0) if genes[left[0]][5] else (left[1] > 0)
+            rfwd = (right[1] < 0) if genes[right[0]][5] else (right[1] > 0)
+            if lfwd != rfwd and not output_untranslated:
+                continue
+            title = "%s%s___%s  (total: %d, unique:%d)" % (
+                "Deletion: " if deletion else "Fusion: ", gene_pos2str(genes[left[0]], left[1]),
+                gene_pos2str(genes[right[0]], right[1]), len(reads), unique)
+            found.append(dict(title=title, left=left, right=right, unique=unique, reads=reads, left_ref=lref,
+                              right_ref=rref, left_ref_ext=lext, right_ref_ext=rext))
+    return sorted(found, key=lambda f: (-f["unique"], -len(f["reads"])))

@@ -1,0 +1,184 @@
+"""clustering, break refinement, qualification and the text / JSON result
+(genefuserust_amd/fusion_result.py) against the independent model (oracle/indexer_model.py) on
+the CPU — the only compute is gf_edit_distance, host code of libgfmatch.so — and end to end
+from files on the GPU.  The reference has no vectors for this step: parity unpinned."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from genefuserust_amd import Fusion, GenePos, ReadMatch
+from genefuserust_amd.fusion_result import (FusionResult, Settings, cluster_matches, dis_connected_count,
+                                            get_ref_seq, group_and_sort, match_group, report_json, report_text)
+from oracle import indexer_model as model
+from tests.helpers import rand_seq, rc
+
+CSV = (">GA,chr1:1000-7000\n1,1000,3000\n2,4000,7000\n\n>GB,chr2:500-6500\n1,500,2500\n2,3500,6500\n\n"
+       ">GR,chr3:100-5100\n1,3100,5100\n2,100,2100\n")
+
+
+def mutate(rng, s: bytes, rate: float) -> bytes:
+    a = bytearray(s)
+    for i in range(len(a)):
+        if rng.random() < rate:
+            a[i] = b"ACGT"[(b"ACGT".index(a[i]) + 1 + int(rng.integers(0, 3))) % 4]
+    return bytes(a)
+
+
+def planted_matches(rng, seqs, lc, lp, rcg, rp, n, jitter=True, gap_free=True):
+    """n reads across the junction (gene lc, last base lp) | (gene rcg, first base rp); positions
+    may be negative (reverse strand of the gene)."""
+    out = []
+    for k in range(n):
+        a, b = int(rng.integers(30, 90)), int(rng.integers(30, 90))
+        left = get_ref_seq(seqs[lc], lp - a + 1, lp)
+        right = get_ref_seq(seqs[rcg], rp, rp + b - 1)
+        assert len(left) == a and len(right) == b
+        seq = mutate(rng, left + right, 0.01)
+        j = int(rng.integers(-2, 3)) if jitter else 0  # the mapper's break may sit a few bases off
+        gap = 0 if (gap_free and k % 4 == 0 and j == 0) else int(rng.integers(1, 3))
+        out.append(ReadMatch(seq, a - 1 + j, GenePos(lc, lp + j), GenePos(rcg, rp + j), gap, 0, 0, bool(k & 1),
+                             b"@read%03d_%d/1" % (k, lc), m_quality=b"F" * len(seq)))
+    return out
+
+
+def to_model(m: ReadMatch):
+    return dict(seq=m.m_read.decode(), brk=m.m_read_break, left=tuple(m.m_left_gp), right=tuple(m.m_right_gp),
+                gap=m.m_gap, ld=m.m_left_distance, rd=m.m_right_distance)
+
+
+def same(fr: FusionResult, mo: dict):
+    assert fr.m_title == mo["title"]
+    assert tuple(fr.m_left_gp) == mo["left"] and tuple(fr.m_right_gp) == mo["right"]
+    assert fr.m_unique == mo["unique"]
+    assert (fr.m_left_ref.decode(), fr.m_right_ref.decode(), fr.m_left_ref_ext.decode(),
+            fr.m_right_ref_ext.decode()) == (mo["left_ref"], mo["right_ref"], mo["left_ref_ext"], mo["right_ref_ext"])
+    assert [(m.m_read_break, tuple(m.m_left_gp), tuple(m.m_right_gp), m.m_left_distance, m.m_right_distance)
+            for m in fr.m_matches] == [(r["brk"], r["left"], r["right"], r["ld"], r["rd"]) for r in mo["reads"]]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_cluster_matches_against_the_model(seed):
+    rng = np.random.default_rng(seed)
+    fusions = Fusion.parse_csv_text(CSV)
+    genes = model.csv_genes(CSV)
+    assert [f.m_gene.m_name for f in fusions] == [g[0] for g in genes] == ["GA", "GB", "GR"]
+    assert fusions[2].is_reversed() and genes[2][5]
+    seqs = [rand_seq(rng, 6000), rand_seq(rng, 6000), rand_seq(rng, 5000)]
+    ms = []
+    ms += planted_matches(rng, seqs, 0, 2500, 1, 3100, 9)                   # GA -> GB, both forward
+    ms += planted_matches(rng, seqs, 1, -3100, 0, -2500, 6)                 # the same junction read off the other strand
+    ms += planted_matches(rng, seqs, 0, 1200, 2, -900, 5)                   # GA -> GR (reversed gene, reverse strand: forward protein)
+    ms += planted_matches(rng, seqs, 0, 1500, 2, 2000, 4)                   # GA -> GR untranslated: dropped by default
+    ms += planted_matches(rng, seqs, 1, 800, 1, 4000, 5)                    # a deletion inside GB: dropped by default
+    ms += planted_matches(rng, seqs, 0, 4200, 1, 700, 1)                    # a single read: unique 1 < 2
+    ms += planted_matches(rng, seqs, 2, 3000, 0, 5000, 5, gap_free=False)   # no gap-free read: mean fusion point
+    # a "fusion" whose two sides continue each other (the same gene both sides, 2 bp apart): can_be_mapped
+    ms += planted_matches(rng, seqs, 1, 5000, 1, 5001, 4)
+    rng.shuffle(ms)
+    groups = group_and_sort(ms, len(fusions))
+    assert [match_group(g[0], 3) for g in groups] == sorted(match_group(g[0], 3) for g in groups)
+    fseq = [s.decode() for s in seqs]
+    for st in (Settings(), Settings(output_deletions=True, output_untranslated=True), Settings(unique_requirement=1)):
+        got = cluster_matches(groups, fusions, fseq, st)
+        want = model.cluster_model([[to_model(m) for m in g] for g in groups], genes, fseq, st.unique_requirement,
+                                   st.output_deletions, st.output_untranslated)
+        assert len(got) == len(want) > 0
+        for fr, mo in zip(got, want):
+            same(fr, mo)
+    got = cluster_matches(groups, fusions, fseq)
+    titles = [fr.m_title for fr in got]
+    assert any(t.startswith("Fusion: GA:intron:1|+chr1:3") and "___GB:exon:2|+chr2:3" in t and "(total: 9, unique:" in t
+               for t in titles), titles  # (3500 | 3600 when a gap-free read names the point, else the mean)
+    assert not any(t.startswith("Deletion") for t in titles)
+    assert len(cluster_matches(groups, fusions, fseq, Settings(output_deletions=True))) > len(got)
+    assert [(-fr.m_unique, -len(fr.m_matches)) for fr in got] == sorted((-fr.m_unique, -len(fr.m_matches)) for fr in got)
+    top = got[0]
+    assert top.m_unique >= 2 and top.m_left_is_exon in (True, False)
+    # the refined break of a clean read sits on the planted junction: left part ends with the left reference
+    for m in top.m_matches:
+        assert m.m_left_distance + m.m_right_distance <= 8  # 1 % substitutions over <= 180 bases
+    # text block: "#title" then one ">k, break:..." record per read (read_match.rs:153-186)
+    txt = report_text(got)
+    assert txt.startswith("\n#" + top.m_title + "\n>1, break:%d, diff:(" % (top.m_matches[0].m_read_break + 1))
+    first = top.m_matches[0]
+    assert "name: %s\n%s %s\n" % (first.m_name[1:].decode(), first.m_read[:first.m_read_break + 1].decode(),
+                                   first.m_read[first.m_read_break + 1:].decode()) in txt
+    # JSON: the reference's writer emits valid JSON; every field is there
+    doc = json.loads(report_json(got, "genefuse -r ref.fa", "0.8.0", "now"))
+    assert doc["command"] == "genefuse -r ref.fa" and list(doc["fusions"]) == titles
+    f0 = doc["fusions"][top.m_title]
+    assert f0["left"]["gene_name"] == top.m_left_gene.m_name and f0["unique"] == top.m_unique
+    assert f0["left"]["position"] == top.m_left_gene.gene_pos_2_chr_pos(top.m_left_gp.position)
+    assert f0["left"]["reference"] == top.m_left_ref.decode() and f0["right"]["strand"] in ("forward", "reversed")
+    assert [r["break"] for r in f0["reads"]] == [m.m_read_break for m in top.m_matches]
+    assert f0["reads"][0]["qual"] == "F" * len(first.m_read)
+
+
+def test_pieces():
+    ref = b"ACGTTGCAAGGCTTAACCGG"
+    assert get_ref_seq(ref, 3, 7) == b"TTGCA" and get_ref_seq(ref, -7, -3) == rc(b"TTGCA")
+    assert get_ref_seq(ref, 0, 4) == b"" and get_ref_seq(ref, -2, 3) == b"" and get_ref_seq(ref, 15, 20) == b""
+    assert dis_connected_count(b"AAAAACCCCC") == 1 and dis_connected_count(b"ACACACACAC") == 9
+    assert FusionResult.can_be_matched(b"", b"ACGT") and FusionResult.can_be_matched(b"ACGTACGTAC", b"")
+    a = rand_seq(np.random.default_rng(5), 60)
+    assert FusionResult.can_be_matched(a, a) and FusionResult.can_be_matched(a[3:] + b"ACG", a)
+    assert not FusionResult.can_be_matched(a, rand_seq(np.random.default_rng(6), 60))
+    with pytest.raises(IndexError):  # the reference's subchars panics when s2 is shorter than the window
+        FusionResult.can_be_matched(a, rand_seq(np.random.default_rng(6), 40))
+    fr = FusionResult()
+    for p, gap in ((100, 2), (103, 1), (101, 3)):
+        fr.add_match(ReadMatch(b"A" * 50, 20, GenePos(0, -p), GenePos(1, p), gap, 0, 0))
+    fr.calc_fusion_point()
+    assert fr.m_left_gp == GenePos(0, -101) and fr.m_right_gp == GenePos(1, 101)  # -304/3 truncates toward zero
+    assert fr.support(ReadMatch(b"A" * 50, 20, GenePos(0, -106), GenePos(1, 100), 0, 0, 0))
+    assert not fr.support(ReadMatch(b"A" * 50, 20, GenePos(0, -107), GenePos(1, 100), 0, 0, 0))
+    assert not fr.support(ReadMatch(b"A" * 50, 20, GenePos(1, -101), GenePos(1, 101), 0, 0, 0))
+
+
+@pytest.mark.gpu
+def test_scan_pair_end_report(gpu_device, tmp_path):
+    """Files in, fusion list out: one planted GA|GB junction covered by 14 pairs at different
+    offsets among background pairs."""
+    from genefuserust_amd.scan import scan_pair_end_report
+    rng = np.random.default_rng(21)
+    chr1, chr2 = rand_seq(rng, 9000), rand_seq(rng, 8000)
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(b">chr1\n" + chr1 + b"\n>chr2\n" + chr2 + b"\n")
+    csv = tmp_path / "f.csv"
+    csv.write_text(">GA,chr1:1000-7000\n1,1000,3000\n2,4000,7000\n\n>GB,chr2:500-6500\n1,500,2500\n2,3500,6500\n")
+    ga, gb = chr1[1000:7000], chr2[500:6500]
+    p, q = 2600, 3300
+    junction = ga[p - 300:p] + gb[q:q + 300]
+    l_txt, r_txt = [], []
+    for k in range(40):
+        if k % 3 == 0:
+            lo = int(rng.integers(100, 230))
+            f = junction[lo:lo + int(rng.integers(200, 270))]
+        else:
+            f = rand_seq(rng, 260)
+        s1, s2 = f[:150], rc(f)[:150]
+        l_txt += [b"@pair%d/1" % k, s1, b"+", b"F" * len(s1)]
+        r_txt += [b"@pair%d/2" % k, s2, b"+", b"F" * len(s2)]
+    r1, r2 = tmp_path / "R1.fq", tmp_path / "R2.fq"
+    r1.write_bytes(b"\n".join(l_txt) + b"\n")
+    r2.write_bytes(b"\n".join(r_txt) + b"\n")
+    results, counters = scan_pair_end_report(str(fa), str(csv), str(r1), str(r2))
+    assert counters["pairs"] == 40 and counters["fusions"] == len(results) >= 1
+    top = results[0]
+    # the junction may slide by a base or two where the genes agree by chance: the same fusion
+    sl = top.m_left_gp.position - (p - 1)
+    assert abs(sl) <= 3 and top.m_left_gp == GenePos(0, p - 1 + sl) and top.m_right_gp == GenePos(1, q + sl)
+    assert ga[p:p + sl] == gb[q:q + sl] if sl > 0 else ga[p + sl:p] == gb[q + sl:q]
+    assert top.m_title.startswith("Fusion: GA:intron:1|+chr1:%d___GB:exon:2|+chr2:%d  (total: " %
+                                  (1000 + p - 1 + sl, 500 + q + sl))
+    assert top.m_unique >= 5 and len(top.m_matches) >= 8
+    pe = p + sl
+    assert top.m_left_ref == ga[pe - len(top.m_left_ref):pe] and top.m_right_ref == gb[q + sl:q + sl + len(top.m_right_ref)]
+    for m in top.m_matches:  # refined: every read breaks at the same junction, no differences left
+        assert m.m_read[:m.m_read_break + 1] == ga[pe - m.m_read_break - 1:pe]
+        assert m.m_left_distance == m.m_right_distance == 0
+    doc = json.loads(report_json(results, "cmd", "0.8.0", "t"))
+    assert doc["fusions"][top.m_title]["left"]["position"] == 1000 + p - 1 + sl
+    assert report_text(results).count("\n>") == sum(len(fr.m_matches) for fr in results)

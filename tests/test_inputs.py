@@ -192,10 +192,12 @@ def test_scan_pair_end_files(gpu_device, tmp_path):
         f.write(b"\n".join(r_txt) + b"\n")
     kept, counters = scan_pair_end_files(str(fa), str(csv), str(r1), str(r2))
     assert counters["pairs"] == 60 and shift == 4
-    names = {m.m_name for m in kept}
+    names = {m.m_name.split(b" merged_diff_")[0] for m in kept}  # (merged reads carry read.rs:372's suffix)
     assert names <= set(planted) and len(names) >= 15
+    assert any(b" merged_diff_" in m.m_name for m in kept)
     for m in kept:
-        p_last, q_first = planted[m.m_name]
+        p_last, q_first = planted[m.m_name.split(b" merged_diff_")[0]]
+        assert len(m.m_quality) == len(m.m_read)
         left, right = (m.m_left_gp, m.m_right_gp)
         assert {left.contig, right.contig} == {0, 1}
         a = left if left.contig == 0 else right
