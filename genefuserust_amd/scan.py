@@ -12,7 +12,7 @@ from __future__ import annotations
 
 from typing import List, Tuple
 
-from .fastq import FastqReaderPair, record_lines
+from .fastq import FastqReader, FastqReaderPair, record_lines
 from .fusion_mapper import FusionMapper, ReadMatch
 from .fusion_result import FusionResult, Settings, cluster_matches, group_and_sort, report_json, report_text
 from .indexer import FastaReader, Fusion, Indexer
@@ -70,5 +70,49 @@ def scan_pair_end_report(ref_file: str, fusion_csv: str, read1_file: str, read2_
                                          settings.deletion_threshold, keep)
     groups = group_and_sort(kept, len(keep["fusions"]))
     results = cluster_matches(groups, keep["fusions"], keep["fusion_seq"], settings)
+    counters["fusions"] = len(results)
+    return results, counters
+
+
+def scan_single_end_files(ref_file: str, fusion_csv: str, read1_file: str, device: int = -1,
+                          deletion_threshold: int = 50, _keep: dict = None) -> Tuple[List[ReadMatch], dict]:
+    """``SingleEndScanner`` (src/core/sescanner.rs:62-195) up to the sorted, filtered match list:
+    every read is mapped, then its reverse complement when it was mapable without a match."""
+    ref = FastaReader(ref_file, True)
+    ref.read_all()
+    fusions = Fusion.parse_csv(fusion_csv)
+    ix = Indexer(ref.m_all_contigs, fusions, device)
+    ix.make_index()
+    try:
+        b, text = FastqReader(read1_file).read_all_device(ix)
+        off = b.offsets.cpu().numpy()
+        bases, quals = b.bases.cpu().numpy().tobytes(), b.quals.cpu().numpy().tobytes()
+        reads = [bases[off[i]:off[i + 1]] for i in range(b.n_records)]
+        mapper = FusionMapper(ix)
+        found: List[ReadMatch] = []
+        for i, m in enumerate(mapper.scan_single_end(reads)):
+            if m is None:
+                continue
+            q = quals[off[i]:off[i + 1]]
+            m.m_quality = q[::-1] if m.m_reversed else q
+            m.m_name = record_lines(b, text, i)[0]
+            m.m_source = "r1"
+            found.append(m)
+        kept, removed = mapper.filter_matches(found, deletion_threshold)
+        counters = {"reads": b.n_records, "matches_before_filtering": len(found), **removed}
+        if _keep is not None:
+            _keep.update(fusions=fusions, fusion_seq=list(ix.m_fusion_seq))
+        return FusionMapper.sort_matches(kept), counters
+    finally:
+        ix.close()
+
+
+def scan_single_end_report(ref_file: str, fusion_csv: str, read1_file: str, device: int = -1,
+                           settings: Settings = None) -> Tuple[List[FusionResult], dict]:
+    """``SingleEndScanner::scan`` up to the reporters: files -> qualified fusions."""
+    settings = settings or Settings()
+    keep: dict = {}
+    kept, counters = scan_single_end_files(ref_file, fusion_csv, read1_file, device, settings.deletion_threshold, keep)
+    results = cluster_matches(group_and_sort(kept, len(keep["fusions"])), keep["fusions"], keep["fusion_seq"], settings)
     counters["fusions"] = len(results)
     return results, counters

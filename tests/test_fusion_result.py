@@ -182,3 +182,10 @@ def test_scan_pair_end_report(gpu_device, tmp_path):
     doc = json.loads(report_json(results, "cmd", "0.8.0", "t"))
     assert doc["fusions"][top.m_title]["left"]["position"] == 1000 + p - 1 + sl
     assert report_text(results).count("\n>") == sum(len(fr.m_matches) for fr in results)
+    # the single-end scanner over R1 alone: the same junction from the reads that reach it
+    from genefuserust_amd.scan import scan_single_end_report
+    se, se_counters = scan_single_end_report(str(fa), str(csv), str(r1))
+    assert se_counters["reads"] == 40 and len(se) >= 1
+    assert se[0].m_left_gp == top.m_left_gp and se[0].m_right_gp == top.m_right_gp
+    assert 2 <= len(se[0].m_matches) <= len(top.m_matches) and all(len(m.m_read) == 150 for m in se[0].m_matches)
+    assert all(m.m_name.endswith(b"/1") and len(m.m_quality) == 150 for m in se[0].m_matches)
