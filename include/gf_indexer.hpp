@@ -78,6 +78,28 @@ struct Gene {  // src/core/gene.rs:16-229
     return ss + m_chr + ":" + std::to_string(pp);
   }
 
+  // :171-203; the out-parameters stay as they were when no exon or intron holds the position.
+  // (The reference never advances its prev_exon: introns are measured against the FIRST exon.)
+  void get_exon_intron(int32_t pos, bool& is_exon, int32_t& number) const {
+    const int32_t pp = (pos < 0 ? -pos : pos) + m_start;
+    for (size_t i = 0; i < m_exons.size(); ++i) {
+      const Exon& e = m_exons[i];
+      if (pp >= e.start && pp <= e.end) {
+        is_exon = true;
+        number = e.id;
+        return;
+      }
+      if (i > 0) {
+        const Exon& p = m_exons[0];
+        if (m_reversed ? (e.end < pp && pp < p.start) : (p.end < pp && pp < e.start)) {
+          is_exon = false;
+          number = e.id - 1;
+          return;
+        }
+      }
+    }
+  }
+
   int32_t gene_pos_2_chr_pos(int32_t genepos) const {  // :205-212
     const int32_t chrpos = (genepos < 0 ? -genepos : genepos) + m_start;
     return genepos < 0 ? -chrpos : chrpos;

@@ -116,6 +116,44 @@ def test_cluster_matches_against_the_model(seed):
     assert f0["reads"][0]["qual"] == "F" * len(first.m_read)
 
 
+def test_cpp_mirror(tmp_path):
+    """include/gf_fusion_result.hpp against the Python mirror: same text block, same JSON bytes."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "genefuserust_amd")
+    exe = str(tmp_path / "test_fr")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "test_fusion_result.cpp"), "-L", lib, "-lgfmatch",
+                    "-Wl,-rpath," + lib, "-o", exe], check=True)
+    rng = np.random.default_rng(11)
+    fusions = Fusion.parse_csv_text(CSV)
+    seqs = [rand_seq(rng, 6000), rand_seq(rng, 6000), rand_seq(rng, 5000)]
+    ms = []
+    ms += planted_matches(rng, seqs, 0, 2500, 1, 3100, 9)
+    ms += planted_matches(rng, seqs, 1, -3100, 0, -2500, 6)
+    ms += planted_matches(rng, seqs, 0, 1200, 2, -900, 5)
+    ms += planted_matches(rng, seqs, 0, 1500, 2, 2000, 4)
+    ms += planted_matches(rng, seqs, 1, 800, 1, 4000, 5)
+    ms += planted_matches(rng, seqs, 2, 3000, 0, 5000, 5, gap_free=False)
+    ms += planted_matches(rng, seqs, 1, 5000, 1, 5001, 4)
+    rng.shuffle(ms)
+    (tmp_path / "f.csv").write_text(CSV)
+    (tmp_path / "seqs.txt").write_bytes(b"\n".join(seqs) + b"\n")
+    (tmp_path / "m.tsv").write_bytes(b"".join(
+        b"\t".join([m.m_name, m.m_read, m.m_quality] + [b"%d" % v for v in (
+            m.m_read_break, m.m_left_gp.contig, m.m_left_gp.position, m.m_right_gp.contig, m.m_right_gp.position,
+            m.m_gap, m.m_left_distance, m.m_right_distance, int(m.m_reversed))]) + b"\n" for m in ms))
+    fseq = [s.decode() for s in seqs]
+    for st in (Settings(), Settings(output_deletions=True, output_untranslated=True), Settings(unique_requirement=1)):
+        out = subprocess.run([exe, str(tmp_path / "f.csv"), str(tmp_path / "seqs.txt"), str(tmp_path / "m.tsv"),
+                              str(st.unique_requirement), str(int(st.output_deletions)),
+                              str(int(st.output_untranslated))], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        got = cluster_matches(group_and_sort(ms, len(fusions)), fusions, fseq, st)
+        assert len(got) >= 3
+        assert out.stdout == report_text(got) + "\n====\n" + report_json(got, "cmd", "v", "t", st)
+
+
 def test_pieces():
     ref = b"ACGTTGCAAGGCTTAACCGG"
     assert get_ref_seq(ref, 3, 7) == b"TTGCA" and get_ref_seq(ref, -7, -3) == rc(b"TTGCA")
