@@ -290,7 +290,12 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 #pragma unroll
       for (int k = 0; k < NT; ++k) e_todo[k] = 0;
       uint32_t w0 = 0, sh = 0;
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 6  // timing only: staging and conversion, one LDS word per read
+      if (in_range) counts[r] = s_pk[((uint32_t)(off0 - base_off) + mis) >> 4] == 0x1234567u ? 1 : 0;
+      if (false) {
+#else
       if (in_range) {
+#endif
         const int64_t len64 = off1 - off0;
         if (len64 > batch_max) {
           counts[r] = GF_COUNT_TOO_LONG;
@@ -351,6 +356,13 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 #if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 1
           if ((nvalid ^ key[0] ^ key[1] ^ key[2] ^ key[3] ^ cwb[0] ^ cwb[1] ^ cwb[2] ^ cwb[NT - 1] ^ okm) == 0x1234567u) counts[r] = 1;
           okm = 0;
+#endif
+#if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 5  // timing only: staging, conversion, the windows and seeds of every read
+          if ((nvalid ^ key[0] ^ key[1] ^ key[2] ^ key[3] ^ cwb[0] ^ cwb[1] ^ cwb[2] ^ cwb[NT - 1] ^ okm) == 0x1234567u) counts[r] = 1;
+          okm = 0;
+          nvalid = 0;
+#pragma unroll
+          for (int k = 0; k < NT; ++k) cwb[k] = 0;
 #endif
           // all four seeds go through the presence filter together (L2 hits).  The 14-mer asked
           // about (bases 32s+2 .. 32s+15) is the last 14 bases of window 16s and the first 14 of

@@ -1,11 +1,15 @@
 #!/bin/bash
 # Timing-only builds of the fused seed+verify kernel (ablations give wrong results by
 # construction; occupancy variants are exact).  build here, run on the GPU box.
-#   GF_ABLATE_SV: 1 = stage + cut words only, 3 = + presence filter, 4 = + seed probes (no verification)
+#   GF_ABLATE_SV: 6 = staging + conversion only, 5 = + the windows and seeds of every read (no look-ups),
+#   noinl = the whole kernel without the inline filter pass (-DGF_SV_NO_INLINE_FILTER: exact, the
+#   background reads go to gf_k_probe_filter instead)
 #   GF_SVS_WAVES_PER_SIMD: register budget of the kernel
+# (GF_ABLATE_SV 1 / 3 / 4 stop after the windows / seed filter / seed probes but leave every read
+#  undecided: their times include 64 bytes of list entry per read.)
 set -e
 REPO=$(cd $(dirname $0)/.. && pwd)
-VARIANTS="sv1:-DGF_ABLATE_SV=1 sv3:-DGF_ABLATE_SV=3 sv4:-DGF_ABLATE_SV=4 w4:-DGF_SVS_WAVES_PER_SIMD=4 w8:-DGF_SVS_WAVES_PER_SIMD=8"
+VARIANTS="sv6:-DGF_ABLATE_SV=6 sv5:-DGF_ABLATE_SV=5 noinl:-DGF_SV_NO_INLINE_FILTER w4:-DGF_SVS_WAVES_PER_SIMD=4 w8:-DGF_SVS_WAVES_PER_SIMD=8"
 if [ "$1" = build ]; then
   for v in $VARIANTS; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 ${v#*:} -shared \
