@@ -148,10 +148,36 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_lens(const int64_t* __res
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = (uint32_t)total;
 }
 
-// offsets[] of the records, then the sequence and quality lines copied a wavefront per
-// record, 256 bytes per step.  A quality line shorter than its sequence is padded with '!'
-// (Phred 0), a longer one is cut: both are counted in *n_bad (the reference does not check,
-// and its fast_merge would panic on the short ones).
+// 16 bytes from any address (the hardware takes unaligned global loads)
+struct __attribute__((packed, aligned(1))) GfBytes16 { uint32_t v[4]; };
+__device__ __forceinline__ uint4 gf_fq_load16(const uint8_t* p) {
+  const GfBytes16 t = *(const GfBytes16*)p;
+  return make_uint4(t.v[0], t.v[1], t.v[2], t.v[3]);
+}
+// bytes 0 .. k-1 of a, bytes k .. 15 of b
+__device__ __forceinline__ uint4 gf_fq_splice16(uint4 a, uint4 b, int k) {
+  uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = k - 4 * j;  // bytes of this dword that come from a
+    const uint32_t m = n >= 4 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << (8 * n)) - 1u));
+    o[j] = (av[j] & m) | (bv[j] & ~m);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// offsets[] of the records, then the sequence and quality lines of a tile of 256 records
+// copied as ONE ragged memcpy per output array: the tile's records are contiguous in `bases`
+// and `quals`, so a thread takes an aligned 16-byte piece of the output, finds the record it
+// falls in (binary search over the tile's offsets in LDS) and fetches its 16 bytes from the
+// text with one unaligned load — two loads spliced when the piece spans the end of one record
+// and the start of the next; the pieces at the tile's edges (shared with the neighbouring
+// blocks) and pieces over more than two records go byte by byte.  Every lane moves 32 bytes
+// per round whatever the read length (a wavefront per record kept 38 of 64 lanes busy with
+// 4 bytes each on 150-base reads).  A quality line shorter than its sequence is padded with
+// '!' (Phred 0), a longer one is cut: both are counted in *n_bad (the reference does not
+// check, and its fast_merge would panic on the short ones); a tile that holds such a record,
+// or that does not fit the caller's buffers, is copied a wavefront per record instead.
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __restrict__ text,
                                                               const int64_t* __restrict__ nl_pos, int64_t n_newlines,
                                                               int64_t n_bytes, int64_t n_rec,
@@ -160,8 +186,10 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __r
                                                               uint8_t* __restrict__ bases, uint8_t* __restrict__ quals,
                                                               int64_t cap_bytes, unsigned long long* __restrict__ n_bad) {
   __shared__ int s_wave[4];
-  __shared__ int64_t s_ss[GF_FQ_RTILE], s_qs[GF_FQ_RTILE], s_dst[GF_FQ_RTILE];
-  __shared__ int s_len[GF_FQ_RTILE], s_qlen[GF_FQ_RTILE];
+  __shared__ int64_t s_ss[GF_FQ_RTILE], s_qs[GF_FQ_RTILE];
+  __shared__ int s_rel[GF_FQ_RTILE + 2], s_qlen[GF_FQ_RTILE];
+  __shared__ int s_odd;
+  if (threadIdx.x == 0) s_odd = 0;
   const int64_t t0 = (int64_t)blockIdx.x * GF_FQ_RTILE;
   const int64_t r = t0 + threadIdx.x;
   int len = 0, qlen = 0;
@@ -174,82 +202,68 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __r
     qlen = (int)(qe - qs);
   }
   int total;
-  const int64_t pos = tile_offsets[blockIdx.x] + gf_block_exclusive_scan(len, s_wave, &total);
+  const int rel = gf_block_exclusive_scan(len, s_wave, &total);  // (its barriers order the s_odd store above)
+  const int64_t pos0 = tile_offsets[blockIdx.x];
   if (r < n_rec) {
-    offsets[r] = pos;
-    if (r == n_rec - 1) offsets[n_rec] = pos + len;
-    if (qlen != len) atomicAdd(n_bad, 1ull);
+    offsets[r] = pos0 + rel;
+    if (r == n_rec - 1) offsets[n_rec] = pos0 + rel + len;
+    if (qlen != len) {
+      atomicAdd(n_bad, 1ull);
+      s_odd = 1;
+    }
   }
-  s_ss[threadIdx.x] = ss; s_qs[threadIdx.x] = qs; s_dst[threadIdx.x] = pos;
-  s_len[threadIdx.x] = len; s_qlen[threadIdx.x] = qlen;
+  s_ss[threadIdx.x] = ss; s_qs[threadIdx.x] = qs;
+  s_rel[threadIdx.x] = rel;  // (threads past the last record hold `total`)
+  s_qlen[threadIdx.x] = qlen;
+  if (threadIdx.x < 2) s_rel[GF_FQ_RTILE + threadIdx.x] = total;
   __syncthreads();
+  const int64_t end = pos0 + total;
+  const bool aligned = (((uintptr_t)bases | (uintptr_t)quals) & 15u) == 0;
+  if (!s_odd && end <= cap_bytes && aligned) {
+    const int64_t c_hi = (end + 15) >> 4;
+    for (int64_t c = (pos0 >> 4) + threadIdx.x; c < c_hi; c += GF_CTHREADS) {
+      const int64_t b0 = c << 4;
+      const int64_t lo = b0 > pos0 ? b0 : pos0, hi = b0 + 16 < end ? b0 + 16 : end;  // this tile's bytes of the piece
+      if (lo >= hi) continue;
+      // the record that holds byte lo: the largest i with s_rel[i] <= x (then s_rel[i + 1] > x)
+      const int x = (int)(lo - pos0);
+      int i = 0, j = GF_FQ_RTILE;
+      while (j - i > 1) {
+        const int mid = (i + j) >> 1;
+        if (s_rel[mid] <= x) i = mid; else j = mid;
+      }
+      const int xb = (int)(b0 - pos0);  // (negative in the tile's first piece when it starts mid-piece)
+      const bool whole = lo == b0 && hi == b0 + 16;
+      const int64_t sa = s_ss[i] + (xb - s_rel[i]), qa = s_qs[i] + (xb - s_rel[i]);
+      if (whole && s_rel[i + 1] >= xb + 16) {
+        *(uint4*)(bases + b0) = gf_fq_load16(text + sa);
+        *(uint4*)(quals + b0) = gf_fq_load16(text + qa);
+      } else if (whole && s_rel[i + 2] >= xb + 16 && qa + 16 <= n_bytes) {
+        // (sa < qa: the sequence line's load cannot run off the text when the quality line's does not;
+        //  the second record's loads start k bytes before its lines, inside the text)
+        const int k = s_rel[i + 1] - xb;  // bytes of record i in this piece, 1 .. 15
+        *(uint4*)(bases + b0) = gf_fq_splice16(gf_fq_load16(text + sa), gf_fq_load16(text + s_ss[i + 1] - k), k);
+        *(uint4*)(quals + b0) = gf_fq_splice16(gf_fq_load16(text + qa), gf_fq_load16(text + s_qs[i + 1] - k), k);
+      } else {
+        for (int64_t b = lo; b < hi; ++b) {
+          const int xx = (int)(b - pos0);
+          while (s_rel[i + 1] <= xx) ++i;
+          bases[b] = text[s_ss[i] + (xx - s_rel[i])];
+          quals[b] = text[s_qs[i] + (xx - s_rel[i])];
+        }
+      }
+    }
+    return;
+  }
+  // the careful path: a wavefront per record
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int in_tile = (int)((n_rec - t0) < GF_FQ_RTILE ? (n_rec - t0) : GF_FQ_RTILE);
-  // each wavefront takes records wave, wave+4, ...; four records per round so that their
-  // loads are in flight together (a record is one load-store round trip otherwise)
-#ifndef GF_FQ_INFLIGHT
-#define GF_FQ_INFLIGHT 4
-#endif
-  for (int i0 = wave; i0 < in_tile; i0 += GF_FQ_INFLIGHT * (GF_CTHREADS / 64)) {
-    bool simple[GF_FQ_INFLIGHT];
-    uint32_t slo[GF_FQ_INFLIGHT], shi[GF_FQ_INFLIGHT], qlo[GF_FQ_INFLIGHT], qhi[GF_FQ_INFLIGHT];
-#pragma unroll
-    for (int u = 0; u < GF_FQ_INFLIGHT; ++u) {
-      const int i = i0 + u * (GF_CTHREADS / 64);
-      simple[u] = false;
-      if (i < in_tile) {
-        const int ln = s_len[i];
-        const int64_t dst = s_dst[i];
-        // the common shape: quality as long as the sequence, at most 64 whole dwords per line
-        simple[u] = s_qlen[i] == ln && ln <= 256 && dst + ln <= cap_bytes;
-        if (simple[u]) {
-          // bases and quals share dst, hence the split into head bytes, dwords and tail bytes
-          const int head = (int)((4u - (uint32_t)((uintptr_t)(bases + dst) & 3u)) & 3u);
-          const int h = head < ln ? head : ln;
-          const int ndw = (ln - h) >> 2;
-          if (lane < ndw) {
-            const uint8_t* a = text + s_ss[i] + h + 4 * lane;
-            const uint8_t* b = text + s_qs[i] + h + 4 * lane;
-            const uint32_t sa = (uint32_t)((uintptr_t)a & 3u), sb = (uint32_t)((uintptr_t)b & 3u);
-            slo[u] = *(const uint32_t*)(a - sa);
-            shi[u] = sa ? *(const uint32_t*)(a - sa + 4) : 0u;
-            qlo[u] = *(const uint32_t*)(b - sb);
-            qhi[u] = sb ? *(const uint32_t*)(b - sb + 4) : 0u;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < GF_FQ_INFLIGHT; ++u) {
-      const int i = i0 + u * (GF_CTHREADS / 64);
-      if (i >= in_tile) continue;
-      const int64_t dst = s_dst[i];
-      const int ln = s_len[i], ql = s_qlen[i];
-      if (dst + ln > cap_bytes) continue;  // (the caller's buffers are too small: offsets still tell how much is needed)
-      const uint8_t* ssrc = text + s_ss[i];
-      const uint8_t* qsrc = text + s_qs[i];
-      if (simple[u]) {
-        const int head = (int)((4u - (uint32_t)((uintptr_t)(bases + dst) & 3u)) & 3u);
-        const int h = head < ln ? head : ln;
-        const int ndw = (ln - h) >> 2;
-        const int tail0 = h + 4 * ndw;
-        if (lane < ndw) {
-          const uint32_t sa = (uint32_t)((uintptr_t)(ssrc + h) & 3u), sb = (uint32_t)((uintptr_t)(qsrc + h) & 3u);
-          ((uint32_t*)(bases + dst + h))[lane] = __builtin_amdgcn_alignbyte(shi[u], slo[u], sa);
-          ((uint32_t*)(quals + dst + h))[lane] = __builtin_amdgcn_alignbyte(qhi[u], qlo[u], sb);
-        }
-        if (lane < h) {
-          bases[dst + lane] = ssrc[lane];
-          quals[dst + lane] = qsrc[lane];
-        }
-        if (lane >= 32 && lane - 32 < ln - tail0) {
-          bases[dst + tail0 + lane - 32] = ssrc[tail0 + lane - 32];
-          quals[dst + tail0 + lane - 32] = qsrc[tail0 + lane - 32];
-        }
-      } else {
-        gf_fq_copy_line(bases + dst, ssrc, ln, lane);
-        for (int k = lane; k < ln; k += 64) quals[dst + k] = k < ql ? qsrc[k] : (uint8_t)'!';
-      }
-    }
+  for (int i = wave; i < in_tile; i += GF_CTHREADS / 64) {
+    const int64_t dst = pos0 + s_rel[i];
+    const int ln = s_rel[i + 1] - s_rel[i], ql = s_qlen[i];
+    if (dst + ln > cap_bytes) continue;  // (the caller's buffers are too small: offsets still tell how much is needed)
+    gf_fq_copy_line(bases + dst, text + s_ss[i], ln, lane);
+    const uint8_t* qsrc = text + s_qs[i];
+    for (int k = lane; k < ln; k += 64) quals[dst + k] = k < ql ? qsrc[k] : (uint8_t)'!';
   }
 }
