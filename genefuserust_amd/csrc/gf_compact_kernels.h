@@ -48,31 +48,50 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_compact_count(const uint8_t*
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = (uint32_t)total;
 }
 
+// exclusive scan of the tile totals by ONE block: 8 consecutive totals per thread (serial),
+// wave scans by shuffle, the 16 wave sums through LDS — 8192 totals per round, two barriers
 __global__ __launch_bounds__(1024) void gf_k_compact_scan(const uint32_t* __restrict__ tile_counts,
                                                           int64_t ntiles,
                                                           int64_t* __restrict__ tile_offsets,
                                                           int64_t* __restrict__ d_total) {
-  __shared__ long long s_part[1024];
-  __shared__ long long s_run;
-  if (threadIdx.x == 0) s_run = 0;
-  __syncthreads();
-  for (int64_t b0 = 0; b0 < ntiles; b0 += 1024) {
-    const int64_t t = b0 + threadIdx.x;
-    long long v = t < ntiles ? (long long)tile_counts[t] : 0;
-    s_part[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
-      long long y = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0;
-      __syncthreads();
-      s_part[threadIdx.x] += y;
-      __syncthreads();
+  constexpr int PER = 8;
+  __shared__ long long s_wsum[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long run = 0;  // sum of all earlier rounds (the same in every thread)
+  for (int64_t b0 = 0; b0 < ntiles; b0 += 1024 * PER) {
+    const int64_t t0 = b0 + (int64_t)threadIdx.x * PER;
+    uint32_t v[PER];
+    long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      v[k] = t0 + k < ntiles ? tile_counts[t0 + k] : 0u;
+      mine += v[k];
     }
-    if (t < ntiles) tile_offsets[t] = s_run + s_part[threadIdx.x] - v;
+    long long x = mine;  // inclusive scan of the threads' sums within the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) s_wsum[wave] = x;
     __syncthreads();
-    if (threadIdx.x == 1023) s_run += s_part[1023];
-    __syncthreads();
+    long long base = run, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const long long ws = s_wsum[w];
+      if (w < wave) base += ws;
+      all += ws;
+    }
+    long long pos = base + x - mine;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (t0 + k < ntiles) tile_offsets[t0 + k] = pos;
+      pos += v[k];
+    }
+    run += all;
+    __syncthreads();  // s_wsum is rewritten in the next round
   }
-  if (threadIdx.x == 0) *d_total = s_run;
+  if (threadIdx.x == 0) *d_total = run;
 }
 
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_compact_write(
