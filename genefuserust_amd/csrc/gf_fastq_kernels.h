@@ -47,19 +47,33 @@ __device__ __forceinline__ void gf_fq_load64(const uint8_t* __restrict__ text, i
   }
 }
 
+// one bit per byte of the thread's 64: bit 4k+b = byte b of dword k is '\n'
+__device__ __forceinline__ uint64_t gf_fq_mask64(const uint32_t (&w)[16]) {
+  uint64_t m = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t f = gf_newline_flags(w[k]);  // bits 7, 15, 23, 31
+    m |= (uint64_t)((((f >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * k);
+  }
+  return m;
+}
+
+// per tile: the number of newlines; per thread: the newline mask of its 64 bytes, kept for
+// gf_k_fq_write (an eighth of the text to read back instead of the text itself)
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_count(const uint8_t* __restrict__ text, int64_t n,
-                                                             uint32_t* __restrict__ tile_counts) {
+                                                             uint32_t* __restrict__ tile_counts,
+                                                             uint64_t* __restrict__ masks) {
   __shared__ int s_wave[4];
   const int64_t p0 = (int64_t)blockIdx.x * GF_FQ_TILE + (int64_t)threadIdx.x * GF_FQ_PER;
-  int c = 0;
+  uint64_t m = 0;
   if (p0 < n) {
     uint32_t w[16];
     gf_fq_load64(text, n, p0, w);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) c += __popc(gf_newline_flags(w[k]));
+    m = gf_fq_mask64(w);
   }
+  masks[(int64_t)blockIdx.x * GF_CTHREADS + threadIdx.x] = m;
   int total;
-  gf_block_exclusive_scan(c, s_wave, &total);
+  gf_block_exclusive_scan(__popcll(m), s_wave, &total);
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = (uint32_t)total;
 }
 
@@ -68,33 +82,21 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_count(const uint8_t* __re
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_write(const uint8_t* __restrict__ text, int64_t n,
                                                              const int64_t* __restrict__ tile_offsets,
                                                              const int64_t* __restrict__ n_newlines,
+                                                             const uint64_t* __restrict__ masks,
                                                              int64_t* __restrict__ nl_pos, int64_t cap,
                                                              int64_t* __restrict__ n_lines) {
   __shared__ int s_wave[4];
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_lines = *n_newlines + ((n > 0 && text[n - 1] != '\n') ? 1 : 0);
   const int64_t p0 = (int64_t)blockIdx.x * GF_FQ_TILE + (int64_t)threadIdx.x * GF_FQ_PER;
-  uint32_t w[16];
-  int c = 0;
-  if (p0 < n) {
-    gf_fq_load64(text, n, p0, w);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      w[k] = gf_newline_flags(w[k]);
-      c += __popc(w[k]);
-    }
-  }
+  uint64_t m = masks[(int64_t)blockIdx.x * GF_CTHREADS + threadIdx.x];
+  const int c = __popcll(m);
   int total;
   int64_t pos = tile_offsets[blockIdx.x] + gf_block_exclusive_scan(c, s_wave, &total);
-  if (!c) return;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    uint32_t f = w[k];
-    while (f) {
-      const int b = __builtin_ctz(f) >> 3;  // byte index inside the dword
-      f &= f - 1;
-      if (pos < cap) nl_pos[pos] = p0 + 4 * k + b;
-      ++pos;
-    }
+  while (m) {
+    const int b = __builtin_ctzll(m);
+    m &= m - 1;
+    if (pos < cap) nl_pos[pos] = p0 + b;
+    ++pos;
   }
 }
 

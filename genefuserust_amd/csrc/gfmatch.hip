@@ -990,9 +990,15 @@ int gf_fast_merge(const gf_index* idx, const char* l_seq, const char* l_qual, in
 // record is at least its four newlines)
 static inline int64_t fq_tiles(int64_t n_bytes) { return n_bytes / (4 * GF_FQ_RTILE) + 2; }
 
+// the tile arrays, then (gf_fastq_index_device only) one newline bit per byte of the text
+static inline int64_t fq_tile_arrays_bytes(int64_t n_bytes) {
+  return (64 + fq_tiles(n_bytes) * (int64_t)(sizeof(uint32_t) + sizeof(int64_t)) + 16 + 15) & ~(int64_t)15;
+}
+static inline int64_t fq_text_tiles(int64_t n_bytes) { return (n_bytes + GF_FQ_TILE - 1) / GF_FQ_TILE; }
+
 int64_t gf_fastq_workspace_bytes(int64_t n_bytes) {
   if (n_bytes < 0) return 0;
-  return 64 + fq_tiles(n_bytes) * (int64_t)(sizeof(uint32_t) + sizeof(int64_t)) + 16;
+  return fq_tile_arrays_bytes(n_bytes) + fq_text_tiles(n_bytes) * (int64_t)(GF_CTHREADS * sizeof(uint64_t)) + 16;
 }
 
 int gf_fastq_index_device(const gf_index* idx, const void* d_text, int64_t n_bytes, void* d_nl_pos, int64_t cap_lines,
@@ -1006,17 +1012,18 @@ int gf_fastq_index_device(const gf_index* idx, const void* d_text, int64_t n_byt
   uintptr_t w = ((uintptr_t)d_workspace + 15) & ~(uintptr_t)15;
   int64_t* tile_offsets = (int64_t*)w;
   uint32_t* tile_counts = (uint32_t*)(w + (size_t)fq_tiles(n_bytes) * sizeof(int64_t));
+  uint64_t* masks = (uint64_t*)(w + (size_t)fq_tile_arrays_bytes(n_bytes));
   int64_t* n_lines = (int64_t*)d_n_lines;  // [0] lines, [1] newlines
   if (ntiles > 0) {
     hipLaunchKernelGGL(gf_k_fq_count, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text, n_bytes,
-                       tile_counts);
+                       tile_counts, masks);
     GF_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, tile_counts, ntiles, tile_offsets, n_lines + 1);
   GF_HIP(hipGetLastError());
   if (ntiles > 0) {
     hipLaunchKernelGGL(gf_k_fq_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text, n_bytes,
-                       tile_offsets, n_lines + 1, (int64_t*)d_nl_pos, cap_lines, n_lines);
+                       tile_offsets, n_lines + 1, (const uint64_t*)masks, (int64_t*)d_nl_pos, cap_lines, n_lines);
     GF_HIP(hipGetLastError());
   } else {
     GF_HIP(hipMemsetAsync(n_lines, 0, sizeof(int64_t), st));
