@@ -206,7 +206,7 @@ __device__ __forceinline__ uint32_t gf_window_mask(int nwin, int k) {
 }
 
 #ifndef GF_SVS_WAVES_PER_SIMD
-#define GF_SVS_WAVES_PER_SIMD 6
+#define GF_SVS_WAVES_PER_SIMD 4  // (four blocks per CU run anyway, see launch_flat: the registers of six are not needed)
 #endif
 template <int PW>
 __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_k_seedverify_stream(
@@ -364,21 +364,40 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 #pragma unroll
           for (int k = 0; k < NT; ++k) cwb[k] = 0;
 #endif
-          // all four seeds go through the presence filter together (L2 hits).  The 14-mer asked
-          // about (bases 32s+2 .. 32s+15) is the last 14 bases of window 16s and the first 14 of
-          // window 16s+1: a clear bit pair proves that neither can vote, which spares the filter
+          // The seeds go through the presence filter before their buckets (L2 hits).  The 14-mer
+          // asked about (bases 32s+2 .. 32s+15) is the last 14 bases of window 16s and the first 14
+          // of window 16s+1: a clear bit pair proves that neither can vote, which spares the filter
           // pass those windows.
           uint32_t kill[2] = {0, 0};  // windows 0..63 proven unable to vote (seeds sit at windows 0, 16, 32, 48)
+          uint32_t K = GF_NONE_LIN;   // candidate diagonal: site code of read base 0
+          // Seed 0 first — filter, then its bucket: most reads that have a candidate diagonal get it
+          // here, for one filter line into the L1 instead of four (the kernel is bound by those line
+          // fills); the other three seeds are asked about only by the reads still without one.
           if (T.bloom_in_l2) {
+            const uint32_t h2 = GF_BLOOM_HASH((key[0] >> 4));
+            const uint32_t fb = GF_BLOOM_BITS(h2);
+            if ((T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)] & fb) != fb) {
+              okm &= ~1u;
+              kill[0] |= 3u;
+            }
+          }
+          if (okm & 1u) {
+            okm &= ~1u;
+            const uint32_t val = gf_lookup(T, key[0]);
+            const uint32_t ty = val >> GF_TYPE_SHIFT;
+            if (ty == GF_TYPE_UNIQUE) K = val & GF_LIN_MASK;
+            else if (ty != GF_TYPE_DUPES) kill[0] |= 1u;
+          }
+          if (K == GF_NONE_LIN && T.bloom_in_l2) {
             uint32_t fw[4], fb[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const uint32_t h2 = GF_BLOOM_HASH((key[s] >> 4));  // the window's last 14 bases
+            for (int s = 1; s < 4; ++s) {
+              const uint32_t h2 = GF_BLOOM_HASH((key[s] >> 4));
               fb[s] = GF_BLOOM_BITS(h2);
-              fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];  // unconditional: always in range
+              fw[s] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 1; s < 4; ++s)
               if (2 * s < PW && (fw[s] & fb[s]) != fb[s]) {
                 okm &= ~(1u << s);
                 kill[s >> 1] |= 3u << (16 * (s & 1));
@@ -390,7 +409,6 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 #endif
           // one bucket probe at a time, in seed order, until one names a diagonal: an
           // on-target read costs one L2-missing request here
-          uint32_t K = GF_NONE_LIN;  // candidate diagonal: site code of read base 0
           while (okm != 0 && K == GF_NONE_LIN) {  // (a wave runs as many rounds as its unluckiest lane needs)
             const int s = __builtin_ctz(okm);
             okm &= okm - 1;

@@ -9,7 +9,7 @@
 #  undecided: their times include 64 bytes of list entry per read.)
 set -e
 REPO=$(cd $(dirname $0)/.. && pwd)
-VARIANTS="sv6:-DGF_ABLATE_SV=6 sv5:-DGF_ABLATE_SV=5 noinl:-DGF_SV_NO_INLINE_FILTER w4:-DGF_SVS_WAVES_PER_SIMD=4 w8:-DGF_SVS_WAVES_PER_SIMD=8"
+VARIANTS="sv6:-DGF_ABLATE_SV=6 sv5:-DGF_ABLATE_SV=5 noinl:-DGF_SV_NO_INLINE_FILTER w6:-DGF_SVS_WAVES_PER_SIMD=6 w8:-DGF_SVS_WAVES_PER_SIMD=8"
 if [ "$1" = build ]; then
   for v in $VARIANTS; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 ${v#*:} -shared \
