@@ -202,9 +202,8 @@ static int launch_flat(const gf_index* idx, hipStream_t st, const uint8_t* bases
                        const FlatPlan& p, hipEvent_t* ev) {
   GF_HIP(hipMemsetAsync(w.ctr, 0, 64, st));
   if (ev) GF_HIP(hipEventRecord(ev[0], st));
-  // Seed+verify is bound by L2-missing requests, not by waves in flight: four blocks per CU
-  // (40 KB of LDS each, padded with dynamic LDS) measured 2.5 % faster than the six its
-  // registers allow.
+  // Seed+verify is bound by the line fills of its CU's L1, not by waves in flight: four blocks
+  // per CU (40 KB of LDS each, padded with dynamic LDS) measured 2.5 % faster than six.
   size_t pad_lds = PW == 10 ? 24000 : 0;
   if (const char* e = getenv("GF_SV_PAD_LDS")) pad_lds = (size_t)atoi(e);  // experiments
   hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(p.nblk), dim3(256), pad_lds, st, idx->table, bases, offsets, n,
