@@ -186,3 +186,56 @@ def test_fastq_cut_full_size_round_trip(small_index):
     # without the final newline the last record still counts; without its last line it does not
     assert fastq_cut_device(small_index, text[:-1]).n_records == n
     assert fastq_cut_device(small_index, text[:-(L + 1)]).n_records == n - 1
+
+
+@pytest.mark.gpu
+def test_gather_through_the_abi_with_awkward_buffers(small_index, oracle):
+    """gf_fastq_gather_device called directly: output buffers that are not 16-byte aligned (the
+    ragged copy's pieces cannot be stored whole: every tile takes the wavefront-per-record
+    path), a text that starts at an odd address, and output buffers too small for all records
+    (the records that fit are copied, `offsets` still tells how much is needed)."""
+    import torch
+    from genefuserust_amd import _lib
+    L, h = _lib.lib(), small_index._handle()
+    t = synth_fastq(11, 4000, lens=(30, 200))
+    want = oracle.fastq_cut(t)
+    dev = torch.device("cuda", small_index.info()["device"])
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for text_shift, out_shift, cap_cut in ((0, 1, 0), (3, 0, 0), (1, 5, 0), (0, 0, 50000), (0, 8, 50000)):
+        raw = torch.zeros(len(t) + 64, dtype=torch.uint8, device=dev)
+        text = raw[text_shift:text_shift + len(t)]
+        text.copy_(torch.frombuffer(bytearray(t), dtype=torch.uint8))
+        n = len(t)
+        ws = torch.empty(int(L.gf_fastq_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        n_lines = torch.zeros(2, dtype=torch.int64, device=dev)
+        nl_pos = torch.empty(n, dtype=torch.int64, device=dev)
+        _lib.check(L.gf_fastq_index_device(h, text.data_ptr(), n, nl_pos.data_ptr(), n, n_lines.data_ptr(),
+                                           ws.data_ptr(), st))
+        lines, newlines = (int(x) for x in n_lines.cpu())
+        n_rec = lines // 4
+        assert n_rec == len(want)
+        total = sum(len(w[1]) for w in want)
+        cap = total - cap_cut
+        offsets = torch.zeros(n_rec + 1, dtype=torch.int64, device=dev)
+        bases_raw = torch.full((total + 64,), 0x2E, dtype=torch.uint8, device=dev)
+        quals_raw = torch.full((total + 64,), 0x2E, dtype=torch.uint8, device=dev)
+        bases, quals = bases_raw[out_shift:], quals_raw[out_shift:]
+        n_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+        _lib.check(L.gf_fastq_gather_device(h, text.data_ptr(), n, nl_pos.data_ptr(), newlines, n_rec,
+                                            offsets.data_ptr(), bases.data_ptr(), quals.data_ptr(), cap,
+                                            n_bad.data_ptr(), ws.data_ptr(), st))
+        torch.cuda.synchronize(dev)
+        off = offsets.cpu().numpy()
+        assert off[-1] == total and int(n_bad.item()) == 0
+        b, q = bases.cpu().numpy().tobytes(), quals.cpu().numpy().tobytes()
+        copied = 0
+        for i, w in enumerate(want):
+            lo, hi = int(off[i]), int(off[i + 1])
+            if hi <= cap:
+                assert b[lo:hi] == w[1] and q[lo:hi] == w[3], (text_shift, out_shift, cap_cut, i)
+                copied += 1
+        assert copied == len(want) if cap_cut == 0 else 0 < copied < len(want)
+        # nothing beyond the capacity handed over is written
+        assert b[cap:cap + 32] == b"." * 32 and q[cap:cap + 32] == b"." * 32
+        if out_shift:
+            assert bases_raw[:out_shift].cpu().numpy().tobytes() == b"." * out_shift
