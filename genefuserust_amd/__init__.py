@@ -11,6 +11,7 @@ from .fusion_mapper import FusionMapper, ReadMatch, edit_distance, reverse_compl
 from .read_pair import MergedRead, SequenceReadPair, fast_merge_batch, fast_merge_device, scan_pair_end  # noqa: F401
 from .fusion_result import (FusionResult, Settings, cluster_matches, group_and_sort, report_json,  # noqa: F401
                             report_text)
+from .matcher import Matcher, MatcherPanic, remove_alignables  # noqa: F401
 from .fastq import FastqBatch, FastqReader, FastqReaderPair, fastq_cut_device, record_lines  # noqa: F401
 
 __version__ = "0.1.0"

@@ -109,6 +109,12 @@ class FusionMapper:
                 removed[names[why]] += 1
         return kept, removed
 
+    def remove_alignables(self, matches: Sequence[ReadMatch]):
+        """fusion_mapper.rs:488-542, the last step of ``filter_matches``, as the reference behaves:
+        (kept, removed).  See matcher.py — it removes nothing, or panics on a small reference."""
+        from .matcher import remove_alignables
+        return remove_alignables(matches, self.m_indexer.get_ref())
+
     @staticmethod
     def sort_matches(matches: Sequence[ReadMatch]) -> List[ReadMatch]:
         """fusion_mapper.rs:378-384: read_break descending, shorter read first, name descending."""

@@ -5,8 +5,9 @@ own file formats: FASTA + fusion CSV -> index; R1/R2 FASTQ -> records -> per-pai
 
 Glue only: every step is one of the mirrors in this package, and all compute goes through
 libgfmatch.so.  ``scan_pair_end_report`` adds the back half (clustering, qualification, text and
-JSON results: SURVEY.md §8(f)-4, ``fusion_result.py``).  ``remove_alignables`` (§8(f)-3) is not
-applied: the reference's ``Matcher`` removes nothing.
+JSON results: SURVEY.md §8(f)-4, ``fusion_result.py``).  ``remove_alignables`` (§8(f)-3, ``matcher.py``:
+the reference's ``Matcher`` as it is — it removes nothing on a genome, and panics on small
+references) is applied only on request.
 """
 from __future__ import annotations
 
@@ -20,7 +21,8 @@ from .read_pair import SequenceReadPair, scan_pair_end
 
 
 def scan_pair_end_files(ref_file: str, fusion_csv: str, read1_file: str, read2_file: str, device: int = -1,
-                        deletion_threshold: int = 50, _keep: dict = None) -> Tuple[List[ReadMatch], dict]:
+                        deletion_threshold: int = 50, _keep: dict = None,
+                        remove_alignables: bool = False) -> Tuple[List[ReadMatch], dict]:
     """Returns (matches kept, in ``sort_matches`` order; counters).  Each match carries the name
     of the read it was found on (for a merged read the R1 name with the " merged_diff_N" suffix of
     read.rs:372)."""
@@ -50,6 +52,8 @@ def scan_pair_end_files(ref_file: str, fusion_csv: str, read1_file: str, read2_f
                     m.m_name += b" merged_diff_%d" % m.m_merge_diff
                 found.append(m)
         kept, removed = mapper.filter_matches(found, deletion_threshold)
+        if remove_alignables:  # (the reference always does: a whole-genome scan that removes nothing)
+            kept, removed["alignables"] = mapper.remove_alignables(kept)
         counters = {"pairs": l.n_records, "matches_before_filtering": len(found), **removed}
         if _keep is not None:
             _keep.update(fusions=fusions, fusion_seq=list(ix.m_fusion_seq))

@@ -468,3 +468,111 @@ def cluster_model(groups, genes, fusion_seq, unique_requirement: int = 2, output
             found.append(dict(title=title, left=left, right=right, unique=unique, reads=reads, left_ref=lref,
                               right_ref=rref, left_ref_ext=lext, right_ref_ext=rext))
     return sorted(found, key=lambda f: (-f["unique"], -len(f["reads"])))
+
+
+# ---- the reference's Matcher as it is (matcher.rs), loop by loop — the
+# `break` that leaves make_kmer at the first base, the roll with the base at the window start,
+# the votes shifted by the site's list index, the inverted contains_key — for the vectorised
+# restatement in genefuserust_amd/matcher.py to be compared with.
+
+class ModelPanic(Exception):
+    pass
+
+
+_M_CODE = {"A": 0, "T": 1, "C": 2, "G": 3}
+
+
+def _m_make_kmer(seq: str, pos: int):
+    kmer = 0
+    for i, base in enumerate(seq[pos:pos + 16]):
+        if base not in _M_CODE:
+            return 0, False
+        kmer += _M_CODE[base]
+        break  # (the reference's `break` leaves the for loop, not a switch)
+    return kmer, True
+
+
+def matcher_model_build(contigs, read_seqs):
+    """-> (bloom bytes as a dict byte -> bits, index: key -> [(ctg, pos)])"""
+    bloom = {}
+    for s in read_seqs:
+        for t in (s, revcomp(s)):
+            if len(t) - 16 + 1 < 0:
+                raise ModelPanic("range")
+            for i in range(len(t) - 16 + 1):
+                kmer, valid = _m_make_kmer(t, i)
+                if valid:
+                    bloom[kmer >> 3] = bloom.get(kmer >> 3, 0) | (1 << (kmer & 7))
+    index = {}
+    for ctg, (name, seq) in enumerate(sorted(contigs.items())):
+        seq = seq.upper()
+        if len(seq) - 16 < 0:
+            raise ModelPanic("slice")
+        kmer, valid = 0, False
+        for i in range(len(seq) - 16):
+            base = seq[i]
+            if valid:
+                if base not in _M_CODE:
+                    valid = False
+                    continue
+                kmer = ((kmer << 2) | _M_CODE[base]) & 0xFFFFFFFF
+            else:
+                kmer, valid = _m_make_kmer(seq, i)
+                if not valid:
+                    continue
+            if not (bloom.get(kmer >> 3, 0) >> (kmer & 7)) & 1:
+                continue
+            index.setdefault(kmer, []).append((ctg, i))
+    return bloom, index
+
+
+def matcher_model_map(index, seq: str):
+    """None, or raises ModelPanic where the reference panics."""
+    n = len(seq)
+    if n - 16 + 1 < 0:
+        raise ModelPanic("range")
+    stat = {0: 0}
+    all_kmer, kmer_valid, skipped = [0] * n, [False] * n, [False] * n
+    for i in range(n - 16 + 1):
+        kmer, valid = _m_make_kmer(seq, i)
+        kmer_valid[i] = valid
+        if not valid:
+            continue
+        all_kmer[i] = kmer
+        if kmer not in index:
+            stat[0] += 1
+            continue
+        if len(index[kmer]) > 50:
+            skipped[i] = True
+            continue
+        for k, (ctg, pos) in enumerate(index[kmer]):
+            g = (ctg << 32) + (pos - k)
+            stat[g] = stat.get(g, 0) + 1
+    topgp, topcount = [0] * 5, [0] * 5
+    for g, cnt in stat.items():
+        if g == 0 or cnt <= topcount[4]:
+            continue
+        topgp[4], topcount[4] = g, cnt
+        for t in range(3, -1, -1):
+            if cnt > topcount[t]:
+                topcount[t + 1], topgp[t + 1] = topcount[t], topgp[t]
+                topcount[t], topgp[t] = cnt, g
+    for t in range(5):
+        if topcount[t] == 0:
+            break
+        mask = [0] * n
+        for i in range(n - 16 + 1):
+            if not kmer_valid[i] or all_kmer[i] in index:
+                continue
+            if not skipped[i]:
+                raise ModelPanic("unwrap on None")  # self.m_kmer_positions.get(&kmer).unwrap()
+            raise ModelPanic("unwrap on None")       # is_consistent's get(..).unwrap()
+        if sum(1 for m in mask if m == 0) < 10:
+            return ("match", topgp[t])
+    return None
+
+
+def matcher_model_do_match(index, seq: str):
+    a = matcher_model_map(index, seq)
+    b = matcher_model_map(index, revcomp(seq))
+    return a if a is not None else b
