@@ -206,3 +206,9 @@ def test_scan_pair_end_files(gpu_device, tmp_path):
         assert abs(abs(a.position) - p_last) <= 4 and abs(abs(b.position) - q_first) <= 4
     order = [(m.m_read_break, len(m.m_read), m.m_name) for m in kept]
     assert order == sorted(order, key=lambda t: (-t[0], t[1], tuple(-c for c in t[2])))
+    # with the reference's last filter step as it is (matcher.py): on a reference this small its
+    # Matcher finds a key with a handful of sites, votes, and panics on the first window whose
+    # key it does not hold — the reference binary would crash on these files
+    from genefuserust_amd import MatcherPanic
+    with pytest.raises(MatcherPanic):
+        scan_pair_end_files(str(fa), str(csv), str(r1), str(r2), remove_alignables=True)
