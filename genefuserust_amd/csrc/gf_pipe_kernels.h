@@ -567,11 +567,18 @@ template <int PW>
 __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW<PW>* __restrict__ list_b,
                                                          const unsigned int* __restrict__ blk_cnt, int64_t per_block,
                                                          uint8_t* __restrict__ counts,
-                                                         unsigned int* __restrict__ blk_cnt2) {
+                                                         unsigned int* __restrict__ blk_cnt2, int phase, int nparts) {
+  // nparts 1: the whole filter in one pass.  A filter larger than an XCD's L2 is asked in nparts
+  // passes instead, each touching one part of its words (which then stays in the L2): phase p
+  // asks the look-ups that fall in part p and leaves the others standing.  A background read
+  // has to ask nearly all of its windows before the gate can stop it, so the split costs it
+  // nothing but the extra trips of its list entry.
   __shared__ unsigned int s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
   const unsigned int nb = blk_cnt[blockIdx.x];
+  const uint32_t part_words = (T.bloom_words + (uint32_t)nparts - 1) / (uint32_t)nparts;
+  const uint32_t part_lo = (uint32_t)phase * part_words, part_hi = part_lo + part_words;
   GfPipeEntryW<PW>* my_list = list_b + (int64_t)blockIdx.x * per_block;
   for (unsigned int t0 = 0; t0 < nb; t0 += 256) {
     const unsigned int t = t0 + threadIdx.x;
@@ -612,8 +619,11 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
               const uint32_t s14 = __builtin_amdgcn_alignbit(pk[j + 1], pk[j], sh14) & 0x0FFFFFFFu;
               const uint32_t h2 = GF_BLOOM_HASH((s14));
               bits[u] = GF_BLOOM_BITS(h2);
-              word[u] = 0;
-              if (both[u]) word[u] = T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)];
+              const uint32_t widx = GF_BLOOM_WORD(h2, T.bloom_words);
+              // (a look-up outside this phase's half stands as if the filter had let it pass)
+              const bool mine = widx >= part_lo && widx < part_hi;
+              word[u] = mine ? 0u : bits[u];
+              if (both[u] && mine) word[u] = T.bloom[widx];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

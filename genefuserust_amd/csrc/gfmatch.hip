@@ -209,11 +209,22 @@ static int launch_flat(const gf_index* idx, hipStream_t st, const uint8_t* bases
   hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(p.nblk), dim3(256), pad_lds, st, idx->table, bases, offsets, n,
                      lmax, batch_max, counts, (GfPipeEntryW<PW>*)w.list_b, w.blk_cnt, p.per_block, w.list_long, w.ctr);
   if (ev) GF_HIP(hipEventRecord(ev[1], st));
-  hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(p.nblk), dim3(256), 0, st, idx->table, (GfPipeEntryW<PW>*)w.list_b,
-                     w.blk_cnt, p.per_block, counts, w.blk_cnt2);
+  // a filter that does not fit an XCD's L2 (bloom_in_l2 == 1) is asked part by part, so that the part
+  // in use stays there (gf_k_probe_filter); GF_FILTER_PARTS sets the number of parts (experiments)
+  static const int parts_env = getenv("GF_FILTER_PARTS") ? atoi(getenv("GF_FILTER_PARTS")) : 0;
+  int nparts = idx->table.bloom_in_l2 == 1 ? 2 : 1;
+  if (parts_env >= 1 && parts_env <= 8 && idx->table.bloom_in_l2 == 1) nparts = parts_env;
+  unsigned int *cnt_in = w.blk_cnt, *cnt_out = w.blk_cnt2;
+  for (int ph = 0; ph < nparts; ++ph) {
+    hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(p.nblk), dim3(256), 0, st, idx->table,
+                       (GfPipeEntryW<PW>*)w.list_b, (const unsigned int*)cnt_in, p.per_block, counts, cnt_out, ph,
+                       nparts);
+    std::swap(cnt_in, cnt_out);
+  }
+  const unsigned int* survivors = cnt_in;  // (the last launch's output)
   if (ev) GF_HIP(hipEventRecord(ev[2], st));
   hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(p.nblk), dim3(256), 0, st, idx->table,
-                     (const GfPipeEntryW<PW>*)w.list_b, w.blk_cnt2, p.per_block, counts, w.list_c, w.ctr);
+                     (const GfPipeEntryW<PW>*)w.list_b, survivors, p.per_block, counts, w.list_c, w.ctr);
   if (ev) GF_HIP(hipEventRecord(ev[3], st));
   if (PW <= 16)
     hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(idx->n_cus * 8), dim3(256), 0, st, idx->table, bases, offsets,
@@ -362,8 +373,8 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   // 3 MiB) so that it lives in every XCD's L2, and seed+verify runs the filter pass for reads
   // without a candidate diagonal itself.  Up to ~38 M keys: 1.75 bits per key, up to
   // GF_BLOOM_MID_KIB (default 8 MiB) — no longer L2-resident, but still mostly L2 hits: used for
-  // the seeds and by the filter kernel (IDX-C, 29 M keys: 4.26 G reads/s; 4.13 with the inline
-  // filter pass, 3.71 with the next form).  Larger indexes: about
+  // the seeds and by the filter kernel, which asks it half by half so that the half in use does
+  // stay in the L2 (IDX-C, 29 M keys: 5.0 G reads/s; 4.65 in one pass).  Larger indexes: about
   // GF_BLOOM_BIG_BPK (default 4) bits per key, resident in the Infinity Cache and used by the
   // filter kernel only — a lookup is then an L2-missing request like a bucket probe, but one
   // lookup answers for two windows and a negative answer spares both bucket probes.
