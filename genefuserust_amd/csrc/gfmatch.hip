@@ -371,7 +371,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   }
   // presence filter over canonical 14-mers.  Indexes up to ~14 M keys: <= GF_BLOOM_KIB (default
   // 3 MiB) so that it lives in every XCD's L2, and seed+verify runs the filter pass for reads
-  // without a candidate diagonal itself.  Up to ~38 M keys: 1.75 bits per key, up to
+  // without a candidate diagonal itself.  Up to ~30 M keys: 2.2 bits per key, up to
   // GF_BLOOM_MID_KIB (default 8 MiB) — no longer L2-resident, but still mostly L2 hits: used for
   // the seeds and by the filter kernel, which asks it half by half so that the half in use does
   // stay in the L2 (IDX-C, 29 M keys: 5.0 G reads/s; 4.65 in one pass).  Larger indexes: about
@@ -386,12 +386,17 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     if (const char* e = getenv("GF_BLOOM_BIG_BPK")) big_bpk = (size_t)atol(e);
     const uint64_t keys = stats[1];
     const uint64_t cap_words = (uint64_t)kib * 1024 / 4, mid_words = (uint64_t)mid_kib * 1024 / 4;
-    const uint64_t want_words = keys * 7 / 128;  // 1.75 bits per key
+    const uint64_t want_words = keys * 7 / 128;  // 1.75 bits per key: what the L2-resident form needs at least
+    // beyond that: 2.2 bits per key — at 1.75 half of the background reads outlive the filter and
+    // go on to the buckets (IDX-C: buckets 0.64 -> 0.37 ms, filter 1.48 -> 1.58 ms per 20 M reads)
+    uint64_t mid_bpk100 = 220;
+    if (const char* e = getenv("GF_BLOOM_BPK100")) mid_bpk100 = (uint64_t)atol(e);  // experiments
+    const uint64_t want_mid = keys * mid_bpk100 / 3200;
     uint64_t words = std::min(std::max<uint64_t>(1024, keys / 2), cap_words);  // up to 16 bits per key
     if (kib > 0 && want_words <= cap_words) {
       bloom_in_l2 = 2;
-    } else if (kib > 0 && want_words <= mid_words) {
-      words = want_words;
+    } else if (kib > 0 && want_mid <= mid_words) {
+      words = want_mid;
       bloom_in_l2 = 1;
     } else if (kib > 0 && big_bpk > 0) {
       words = std::min<uint64_t>(keys * big_bpk / 32 + 1024, (64ull << 20) / 4);
