@@ -62,6 +62,7 @@ def main() -> None:
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--shape", default="IDX-D", choices=["IDX-T", "IDX-D", "IDX-C"])
     ap.add_argument("--mix", default="PANEL", choices=["PANEL", "WGS"])
+    ap.add_argument("--scale", type=float, default=1.0, help="scale of the synthetic gene set (experiments; 1.0 = the named shape)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -106,7 +107,7 @@ def main() -> None:
     # ---- inputs: index (replicated: every rank builds it) + this rank's shard of reads ----
     L = args.read_len
     n = 2 * args.pairs
-    genes = synth.make_geneset(args.shape)
+    genes = synth.make_geneset(args.shape, scale=args.scale)
     t0 = time.time()
     ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags, device=local_rank)
     ix.make_index()
