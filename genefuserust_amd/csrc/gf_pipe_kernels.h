@@ -219,12 +219,12 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
   // front, counter ctr[2]; longer from the back, counter ctr[3]); beyond batch_max: marked.
   constexpr int TILE_BYTES = 64 * 16 * PW;         // ASCII bytes staged per tile (64 reads of 16*PW bases)
   constexpr int TILE_CHUNKS = TILE_BYTES / 16 + 1;  // +1: the span starts at a 16-byte boundary at or below its first read
-  constexpr int PK_WORDS = TILE_CHUNKS + PW + 2;
+  constexpr int PK_WORDS = (TILE_CHUNKS + PW + 2 + 3) & ~3;  // (whole 16-byte vectors: the tile doubles as the entries' staging area)
   constexpr int IV_WORDS = (TILE_CHUNKS + PW + 2) / 2 + 2;
   constexpr int NLOAD = (TILE_CHUNKS + 63) / 64;    // 16-byte chunks per lane per tile
   constexpr int IW = (PW + 1) / 2;                  // 32-base words of flag bits per read
   constexpr int NT = GfPipeEntryW<PW>::NT;          // words of one bit per stride-2 window
-  __shared__ uint32_t s_pk_all[4][PK_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pk_all[4][PK_WORDS];
   __shared__ uint32_t s_iv_all[4][IV_WORDS];
   __shared__ unsigned int s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
@@ -531,12 +531,55 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       }
       __builtin_amdgcn_sched_barrier(0);
       const unsigned int slot_b = gf_wave_append_lds(undecided, &s_cnt);
-      if (undecided) {
-        uint32_t pkw[PW + 1];
+#ifdef GF_ENTRY_DIRECT_STORE
+      constexpr bool direct_store = true;
+#else
+      constexpr bool direct_store = PW > 16;  // (the 20-word form has no registers to spare for the staging)
+#endif
+      if constexpr (direct_store) {
+        if (undecided) {
+          uint32_t pkw[PW + 1];
 #pragma unroll
-        for (int j = 0; j < PW; ++j) pkw[j] = gf_cut_pk(s_pk, w0, sh, j);
-        pkw[PW] = 0;
-        gf_entry_store<PW>(my_list + slot_b, (uint32_t)r, e_v1v2, e_todo, pkw);
+          for (int j = 0; j < PW; ++j) pkw[j] = gf_cut_pk(s_pk, w0, sh, j);
+          pkw[PW] = 0;
+          gf_entry_store<PW>(my_list + slot_b, (uint32_t)r, e_v1v2, e_todo, pkw);
+        }
+      } else {
+      // The wave's entries are neighbours in the list: they go through the (now dead) LDS tile so
+      // that a store instruction writes 1 KB of consecutive bytes instead of 16 bytes every 64
+      // (a lane storing its own entry covers a quarter of each line per instruction).
+      const uint64_t um = __ballot(undecided);
+      if (um) {
+        constexpr int EW = GfPipeEntryW<PW>::EW;
+        constexpr int CH = PK_WORDS / (4 * EW);  // entries the tile holds
+        const int cnt = __popcll(um), rank = gf_lanes_below(um);
+        const unsigned int base =
+            (unsigned int)__builtin_amdgcn_readlane((int)(slot_b - (unsigned int)rank), __builtin_ctzll(um));
+        uint32_t ew[4 * EW];
+#pragma unroll
+        for (int j = 0; j < 4 * EW; ++j) ew[j] = 0;
+        if (undecided) {
+          ew[0] = (uint32_t)r;
+          ew[1] = e_v1v2;
+#pragma unroll
+          for (int k = 0; k < NT; ++k) ew[2 + k] = e_todo[k];
+#pragma unroll
+          for (int j = 0; j < PW; ++j) ew[2 + NT + j] = gf_cut_pk(s_pk, w0, sh, j);
+        }
+        uint4* s_ent = (uint4*)s_pk;
+        for (int c0 = 0; c0 < cnt; c0 += CH) {
+          gf_wave_lds_sync();  // every lane has cut its words / the previous chunk has been read
+          if (undecided && rank >= c0 && rank < c0 + CH) {
+#pragma unroll
+            for (int j = 0; j < EW; ++j)
+              s_ent[(rank - c0) * EW + j] = make_uint4(ew[4 * j], ew[4 * j + 1], ew[4 * j + 2], ew[4 * j + 3]);
+          }
+          gf_wave_lds_sync();
+          const int nvec = (cnt - c0 < CH ? cnt - c0 : CH) * EW;
+          uint4* dst = (uint4*)(my_list + base + c0);
+          for (int k = lane; k < nvec; k += 64) dst[k] = s_ent[k];
+        }
+      }
       }
       if (batch_max > lmax) {  // (wave-uniform) batches with longer reads only
         const unsigned int s1 = gf_wave_append(long1k, ctr + 2);
