@@ -1,17 +1,26 @@
 #!/usr/bin/env python
 """Headline benchmark: 150-bp reads/s through Indexer::map_read on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3,4}]
 
-One "step" = one pass of the hot path over one batch of synthetic reads already
-resident in HBM: the mapping kernel (K2/K3), the ordered hit compaction (K4) and,
-for N > 1, the all-gather of the per-rank hit lists (the path's only exchange).
-Workload at N = 1 is BASELINE.json configs[1]: 10 M synthetic 150-bp pairs
-(20 M reads) against the druggable-shaped index (IDX-D).  For
-N > 1 every rank holds its own 20 M-read shard of a global batch (weak scaling),
-one process per GPU, launched by torch.distributed.run.
+One "step" = one pass of the hot path over one batch of synthetic reads already resident in
+HBM: the mapping kernels (K2/K3), the ordered hit compaction (K4) and, for N > 1, the
+all-gather of the per-rank hit lists (the path's only exchange).  --config picks the workload
+(numbers = index into BASELINE.json `configs`):
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+  1 (default)  10 M synthetic 150-bp pairs (20 M reads) per GPU vs the druggable-shaped index
+               (IDX-D).  N > 1: every rank holds its own 20 M-read shard — weak scaling.
+  2            100 M pairs (200 M reads) vs the cancer-shaped index (IDX-C) on one GPU
+               (N > 1: the same 200 M reads sharded — strong scaling).
+  3            100 M pairs vs IDX-D, read-sharded over the N ranks (25 M reads per rank at
+               N = 8), one all-gather of the hit lists per step — strong scaling.
+  4            multi-CSV mode: 50 M resident reads, 16 fusion CSVs alternating IDX-C / IDX-D;
+               a step rebuilds the index for every CSV a rank owns and maps the reads against it
+               (genefuserust_amd/multi_csv.py: CSV k -> rank k % N, no collective when there are
+               at least N CSVs).  value = (reads x CSVs) / s, index rebuilds inside the timed region.
+
+One process per GPU, launched by torch.distributed.run for N > 1.  Rank 0 prints ONE JSON
+line (see DESIGN.md "Measurement").
 """
 import argparse
 import json
@@ -24,6 +33,19 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_READ_150 = 706  # 150 + 8 + 8*68 + 4
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+CONFIGS = {
+    # shape, pairs (per rank when weak, total when strong), scaling, seed index (20240115 + config_idx)
+    1: dict(shape="IDX-D", pairs=10_000_000, scaling="weak", name="BASELINE configs[1]"),
+    2: dict(shape="IDX-C", pairs=100_000_000, scaling="strong", name="BASELINE configs[2]"),
+    3: dict(shape="IDX-D", pairs=100_000_000, scaling="strong", name="BASELINE configs[3]"),
+    4: dict(shape="IDX-C/IDX-D x16", pairs=25_000_000, scaling="strong", name="BASELINE configs[4]"),
+}
+SHAPE_TEXT = {"IDX-D": "druggable.hg38-shaped: first 32 gene spans of testdata/cancer.csv",
+              "IDX-C": "cancer.hg38-shaped: all 136 gene spans of testdata/cancer.csv",
+              "IDX-T": "the 4 gene spans of testdata/fusions.csv"}
+READS_TEXT = ("reads are independent draws (40 % background / 59.9 % single-gene / 0.1 % junction for PANEL), half of "
+              "them reverse-complemented — mate-like orientation, not N(300,30) fragment pairs: the metric is per read")
 
 
 def algo_bytes_per_read(L: int) -> int:
@@ -53,29 +75,52 @@ def usable_cores() -> int:
     return cores
 
 
+def traffic_entry(shape: str, n: int, L: int):
+    """Counter-measured fabric bytes per launch for this workload (profiles/hbm_traffic.json), or None."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        tj = json.load(open(tpath))
+        return tj.get("%s_%d_%d" % (shape, n, L))
+    except Exception:
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per rank per step")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json configs[] index")
+    ap.add_argument("--pairs", type=int, default=None, help="override: read pairs (per rank for config 1, total otherwise)")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--shape", default="IDX-D", choices=["IDX-T", "IDX-D", "IDX-C"])
+    ap.add_argument("--shape", default=None, choices=["IDX-T", "IDX-D", "IDX-C"], help="override the config's gene set")
     ap.add_argument("--mix", default="PANEL", choices=["PANEL", "WGS"])
     ap.add_argument("--scale", type=float, default=1.0, help="scale of the synthetic gene set (experiments; 1.0 = the named shape)")
+    ap.add_argument("--repeat-frac", type=float, default=None, help="fraction of every gene overwritten by repeat-family copies (default 0.02)")
+    ap.add_argument("--low-complexity", type=float, default=0.0, help="fraction of every gene overwritten by poly-A / tandem-repeat stretches")
+    ap.add_argument("--n-csv", type=int, default=16, help="config 4: fusion CSVs in the list")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--variant", type=int, default=0, help="first pass: 0 flat pipeline (default), 1 wave-per-read probe-all, 2 wave-per-read seed+verify")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.shape:
+        cfg["shape"] = args.shape
+    if args.pairs:
+        cfg["pairs"] = args.pairs
+    if args.steps is None:
+        args.steps = {1: 10, 2: 5, 3: 5, 4: 2}[args.config]
+    if args.warmup is None:
+        args.warmup = {1: 2, 2: 1, 3: 1, 4: 1}[args.config]
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
     from genefuserust_amd import Indexer, synth
-    from genefuserust_amd.dist import allgather_hits
-    from genefuserust_amd.indexer import hits_to_numpy
+    from genefuserust_amd.dist import allgather_hits, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,10 +149,21 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- inputs: index (replicated: every rank builds it) + this rank's shard of reads ----
     L = args.read_len
-    n = 2 * args.pairs
-    genes = synth.make_geneset(args.shape, scale=args.scale)
+    gene_kw = {}
+    if args.repeat_frac is not None:
+        gene_kw["repeat_frac"] = args.repeat_frac
+    if args.low_complexity:
+        gene_kw["low_complexity_frac"] = args.low_complexity
+    seed = 20240115 + args.config
+    if args.config == 4:
+        return bench_multi_csv(args, cfg, world, rank, local_rank, dev, barrier, seed, gene_kw, rehearsal)
+
+    # ---- inputs: index (replicated: every rank builds it) + this rank's shard of reads ----
+    total_reads = 2 * cfg["pairs"] * (world if cfg["scaling"] == "weak" else 1)
+    lo, hi = shard_range(total_reads, rank, world)   # contiguous shard of the global batch
+    n = hi - lo
+    genes = synth.make_geneset(cfg["shape"], scale=args.scale, **gene_kw)
     t0 = time.time()
     ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags, device=local_rank)
     ix.make_index()
@@ -115,10 +171,10 @@ def main() -> None:
     t_index = time.time() - t0
     ix.set_map_variant(args.variant)
     info = ix.info()
-    reads = synth.make_reads(genes, n, read_len=L, mix=args.mix, seed=20240116 + rank, device=str(dev))
+    reads = synth.make_reads(genes, n, read_len=L, mix=args.mix, seed=seed + 1000 * rank, device=str(dev))
     counts = torch.empty(n, dtype=torch.uint8, device=dev)
     matches = torch.empty((n, 2, 4), dtype=torch.int32, device=dev)
-    read_id_base = rank * n
+    read_id_base = lo
     stream = torch.cuda.current_stream(dev)
 
     # N > 1: the per-rank hit lists are merged by one asynchronous all-gather per step
@@ -126,12 +182,14 @@ def main() -> None:
     # exchange of step k overlaps the mapping of step k+1; every step's merged list is finished
     # (waited for and packed on the device) inside the timed region.
     exch = None
+    exchange_name = "none (single GPU)"
     if world > 1:
         if rehearsal or os.environ.get("GF_BENCH_PLAIN_ALLGATHER") == "1":
-            exch = None  # gloo on host copies (or asked for): the plain allgather_hits path
+            exchange_name = "allgather_hits (counts, then padded records; host round trip)"
         else:
             from genefuserust_amd.dist import HitExchange
             exch = HitExchange(cap=max(4096, n // 512), device=dev)
+            exchange_name = "HitExchange (one asynchronous fixed-capacity all-gather, pipelined one step deep)"
     pending = []
 
     def step(ev=None):
@@ -165,6 +223,7 @@ def main() -> None:
             raise
         print("HitExchange failed (%s): falling back to allgather_hits" % e, file=sys.stderr)
         exch = None
+        exchange_name = "allgather_hits (FALLBACK: HitExchange raised %s in warm-up)" % type(e).__name__
         pending.clear()
         for _ in range(args.warmup):
             step()
@@ -199,8 +258,7 @@ def main() -> None:
         names = ["gf_k_seedverify_stream", "gf_k_probe_filter", "gf_k_probe_buckets", "gf_k_map_reads_list"]
         stage_ms = {k: round(a / reps, 4) for k, a in zip(names, acc) if k}
 
-    total_reads = n * world * args.steps
-    value = total_reads / elapsed
+    value = total_reads * args.steps / elapsed
     if world == 1:
         n_hits_total = int(out[1].item())
     elif isinstance(out, tuple):  # HitExchange: (merged, total, overflow)
@@ -210,7 +268,7 @@ def main() -> None:
         n_hits_total = int(out.shape[0])
 
     result = {
-        "metric": "150bp_reads_per_s_map_read_vs_druggable_shaped_index",
+        "metric": "150bp_reads_per_s_map_read_vs_%s_shaped_index" % {"IDX-D": "druggable", "IDX-C": "cancer", "IDX-T": "testdata"}[cfg["shape"]],
         "value": value,
         "unit": "reads/s",
         "n_gpus": world,
@@ -218,62 +276,34 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": cfg["scaling"],
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL on one GPU over gloo: not a measurement)",
         "config": {
-            "workload": "%s: %d synthetic %d-bp read pairs (%d reads) per GPU vs %s (%s, %d bp), mix %s"
-                        % ({"IDX-D": "BASELINE configs[1]", "IDX-C": "BASELINE configs[2] shape",
-                            "IDX-T": "BASELINE configs[0] gene set"}[args.shape], args.pairs, L, n, args.shape,
-                           {"IDX-D": "druggable.hg38-shaped: first 32 gene spans of testdata/cancer.csv",
-                            "IDX-C": "cancer.hg38-shaped: all 136 gene spans of testdata/cancer.csv",
-                            "IDX-T": "the 4 gene spans of testdata/fusions.csv"}[args.shape],
-                           info["total_bp"], args.mix),
+            "workload": "%s: %d synthetic %d-bp read pairs (%d reads) %s vs %s (%s, %d bp), mix %s; %s"
+                        % (cfg["name"] if not (args.shape or args.pairs) else cfg["name"] + " (overridden)",
+                           total_reads // 2, L, total_reads,
+                           "in total, %d reads on each of %d ranks" % (n, world) if world > 1 else "on one GPU",
+                           cfg["shape"], SHAPE_TEXT[cfg["shape"]], info["total_bp"], args.mix, READS_TEXT),
+            "baseline_config": args.config,
             "reads_per_gpu_per_step": n,
             "read_len": L,
-            "index_shape": args.shape,
+            "index_shape": cfg["shape"],
             "index_keys": info["n_keys"],
             "index_table_bytes": info["table_bytes"],
             "index_build_s": round(t_index, 3),
             "hits_per_step": n_hits_total,
+            "exchange": exchange_name,
             "parallelism": "reads sharded over %d rank(s), index replicated, all-gather of hit records" % world
                            if world > 1 else "single GPU",
         },
     }
+    if gene_kw:
+        result["config"]["gene_synthesis"] = gene_kw
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (gf_k_map_reads) ----
-        algo = algo_bytes_per_read(L) * n  # bytes per launch
-        achieved = algo / (kern_ms_avg * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = "%s_%d_%d" % (args.shape, n, L)
-                if key in tj:
-                    traffic = tj[key]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
-        result["roofline"] = {
-            "bound": "hbm",
-            "kernel": {0: "gf_map_reads_device = 4 kernels: gf_k_seedverify_stream + gf_k_probe_filter + "
-                          "gf_k_probe_buckets + gf_k_map_reads_list; achieved uses their summed duration",
-                       1: "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
-                       2: "gf_k_map_reads_short<4,1> (wave per read, seed+verify)"}[args.variant],
-            "stage_ms": stage_ms,
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "algorithmic_bytes_per_read": algo_bytes_per_read(L),
-            "reads_per_launch": n,
-            "kernel_ms_avg": kern_ms_avg,
-            "kernel_reads_per_s": n / (kern_ms_avg * 1e-3),
-        }
-
+        result["roofline"] = roofline_object(args, cfg, n, L, kern_ms_avg, stage_ms)
         # ---- parity spot check + CPU baseline (oracle = CPU restatement; never on the product path) ----
         want_cpu = world == 1 and not args.no_cpu_baseline
         want_parity = not args.no_parity
@@ -293,37 +323,251 @@ def main() -> None:
                 ok = ok and bool((gm[nz, 0] == om[nz, 0]).all()) and bool((gm[oc == 2, 1] == om[oc == 2, 1]).all())
                 result["parity"] = {"checked_reads": ns, "bit_exact": ok, "reads_with_segments": int(nz.sum())}
             if want_cpu:
-                # bounded sample: time a probe, then size the sample for ~cpu_seconds of CPU work
-                probe = min(n, 200_000)
-                b = reads.bases[: probe * L].cpu().numpy()
-                o = reads.offsets[: probe + 1].cpu().numpy()
-                t1 = time.perf_counter()
-                ox.map_reads_packed(b, o, threads=cores)
-                rate = probe / (time.perf_counter() - t1)
-                ns = int(min(n, max(probe, rate * args.cpu_seconds)))
-                b = reads.bases[: ns * L].cpu().numpy()
-                o = reads.offsets[: ns + 1].cpu().numpy()
-                t1 = time.perf_counter()
-                ox.map_reads_packed(b, o, threads=cores)
-                dt = time.perf_counter() - t1
-                t4 = None
-                if cores >= 4:
-                    ns4 = max(1, ns // max(1, cores // 4))
-                    t1 = time.perf_counter()
-                    ox.map_reads_packed(b[: ns4 * L], o[: ns4 + 1], threads=4)
-                    t4 = ns4 / (time.perf_counter() - t1)
-                result["cpu_baseline"] = {
-                    "value": ns / dt,
-                    "unit": "reads/s",
-                    "cores": cores,
-                    "kind": "port",
-                    "sample": "first %d reads of the same batch, oracle/indexer_oracle.cc (CPU restatement of the "
-                              "reference algorithm: 2^32-bit bitmap + hash map + ordered vote map, one read per call, "
-                              "%d threads pulling 1000-read packs); %.1f s" % (ns, cores, dt),
-                    "value_4_threads": t4,
-                }
+                result["cpu_baseline"] = cpu_baseline(ox, reads, n, L, cores, args.cpu_seconds)
+        if world == 1 and not args.no_h2d:
+            try:
+                result["h2d_inclusive"] = h2d_inclusive(ix, reads, n, L)
+            except Exception as e:  # noqa: BLE001 — a reported extra, never the value
+                result["h2d_inclusive"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(result), flush=True)
 
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline_object(args, cfg, n, L, kern_ms_avg, stage_ms):
+    """`achieved`/`frac` follow the contract: ALGORITHMIC bytes (706 B per 150-bp read, of
+    which 544 B are 'one 8-byte index slot per probe' that this design never fetches) over the summed
+    duration of the pass's kernels.  That is NOT the bandwidth the memory system delivers: `traffic`
+    (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/hbm_traffic.json) over the same time is
+    `measured_GBps` / `traffic_frac`, and that is the figure to read as "fraction of HBM peak in use"."""
+    algo = algo_bytes_per_read(L) * n  # bytes per launch
+    achieved = algo / (kern_ms_avg * 1e-3) / 1e9
+    te = traffic_entry(cfg["shape"], n, L) if args.scale == 1.0 and args.mix == "PANEL" else None
+    traffic = te["hbm_bytes_per_launch"] if te else None
+    measured = traffic / (kern_ms_avg * 1e-3) / 1e9 if traffic else None
+    return {
+        "bound": "hbm",
+        "binding_resource": "not HBM streaming: VALU issue and L1 line fills of scattered 4-byte filter look-ups "
+                            "(DESIGN.md §5/§9); the pass moves a third of the algorithmic bytes",
+        "kernel": {0: "gf_map_reads_device = 4 kernels: gf_k_seedverify_stream + gf_k_probe_filter + "
+                      "gf_k_probe_buckets + gf_k_map_reads_list; achieved uses their summed duration",
+                   1: "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
+                   2: "gf_k_map_reads_short<4,1> (wave per read, seed+verify)"}[args.variant],
+        "stage_ms": stage_ms,
+        "achieved": achieved,
+        "algorithmic_GBps": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "frac_definition": "algorithmic bytes / kernel time / 8 TB/s (the contract's formula); see traffic_frac for measured bytes",
+        "traffic": traffic,
+        "traffic_source": (te or {}).get("source"),
+        "measured_GBps": measured,
+        "traffic_frac": measured / HBM_PEAK_GBS if measured else None,
+        "algorithmic_bytes_per_read": algo_bytes_per_read(L),
+        "reads_per_launch": n,
+        "kernel_ms_avg": kern_ms_avg,
+        "kernel_reads_per_s": n / (kern_ms_avg * 1e-3),
+    }
+
+
+def cpu_baseline(ox, reads, n, L, cores, cpu_seconds):
+    # bounded sample: time a probe, then size the sample for ~cpu_seconds of CPU work
+    probe = min(n, 200_000)
+    b = reads.bases[: probe * L].cpu().numpy()
+    o = reads.offsets[: probe + 1].cpu().numpy()
+    t1 = time.perf_counter()
+    ox.map_reads_packed(b, o, threads=cores)
+    rate = probe / (time.perf_counter() - t1)
+    ns = int(min(n, max(probe, rate * cpu_seconds)))
+    b = reads.bases[: ns * L].cpu().numpy()
+    o = reads.offsets[: ns + 1].cpu().numpy()
+    t1 = time.perf_counter()
+    ox.map_reads_packed(b, o, threads=cores)
+    dt = time.perf_counter() - t1
+    t4 = None
+    if cores >= 4:
+        ns4 = max(1, ns // max(1, cores // 4))
+        t1 = time.perf_counter()
+        ox.map_reads_packed(b[: ns4 * L], o[: ns4 + 1], threads=4)
+        t4 = ns4 / (time.perf_counter() - t1)
+    return {
+        "value": ns / dt,
+        "unit": "reads/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "first %d reads of the same batch, oracle/indexer_oracle.cc (CPU restatement of the "
+                  "reference algorithm: 2^32-bit bitmap + hash map + ordered vote map, one read per call, "
+                  "%d threads pulling 1000-read packs); %.1f s" % (ns, cores, dt),
+        "value_4_threads": t4,
+    }
+
+
+def h2d_inclusive(ix, reads, n, L):
+    """PCIe-inclusive rate (SURVEY.md §8d asks for it beside the kernel-only figure; never `value`): the
+    same reads starting in pinned host memory, through the double-buffered streaming entry
+    (gf_stream_*: copy of pack k+1 overlaps the kernels of pack k), hit records back on the host."""
+    import numpy as np
+    import torch
+    from genefuserust_amd.stream import MapStream, pinned_empty
+    ns = min(n, 8_000_000)
+    pack = 1_000_000
+    hb = pinned_empty(ns * L, np.uint8)
+    ho = pinned_empty(ns + 1, np.int64)
+    hb[:] = reads.bases[: ns * L].cpu().numpy()
+    ho[:] = reads.offsets[: ns + 1].cpu().numpy()
+    out = {}
+    with MapStream(ix, max_reads=pack, max_bytes=pack * L + 64, depth=3) as ms:
+        for rep in range(2):  # the first pass warms the arenas
+            t0 = time.perf_counter()
+            total = 0
+            inflight = 0
+            for p0 in range(0, ns, pack):
+                p1 = min(ns, p0 + pack)
+                if inflight == ms.depth:
+                    total += ms.collect().shape[0]
+                    inflight -= 1
+                ms.submit(hb, ho[p0:p1 + 1], read_id_base=p0)
+                inflight += 1
+            while inflight:
+                total += ms.collect().shape[0]
+                inflight -= 1
+            dt = time.perf_counter() - t0
+        out = {"reads_per_s": ns / dt, "host_GBps": (ns * L + 8 * (ns + 1)) / dt / 1e9, "reads": ns, "pack_reads": pack,
+               "hits": int(total), "bytes_per_read": L + 8,
+               "entry": "gf_stream_submit/collect, pinned host buffers, depth 3"}
+    # the link alone: one large pinned H2D copy
+    d = torch.empty(ns * L, dtype=torch.uint8, device=reads.bases.device)
+    t = torch.from_numpy(hb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d.copy_(t, non_blocking=True)
+    torch.cuda.synchronize()
+    out["link_GBps_one_copy"] = ns * L / (time.perf_counter() - t0) / 1e9
+    return out
+
+
+def bench_multi_csv(args, cfg, world, rank, local_rank, dev, barrier, seed, gene_kw, rehearsal):
+    """BASELINE configs[4]: index rebuilt per CSV over a resident read set (fusion_scan.rs:62-188)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from genefuserust_amd import Indexer, synth
+    from genefuserust_amd.multi_csv import plan_multi_csv
+    from genefuserust_amd.dist import allgather_hits
+    L = args.read_len
+    n = 2 * cfg["pairs"]
+    n_csv = args.n_csv
+    shapes = ["IDX-C" if k % 2 == 0 else "IDX-D" for k in range(n_csv)]
+    # CSV k = its shape's gene spans filled from its own seed: 16 different indexes, two sizes
+    jobs = plan_multi_csv(n_csv, n, rank, world)
+    sets = {j.csv: synth.make_geneset(shapes[j.csv], scale=args.scale, seed=1000 + 37 * j.csv, **gene_kw) for j in jobs}
+    # the resident reads: drawn from CSV 0's and CSV 1's genes (every rank holds the same set)
+    base_sets = [synth.make_geneset(shapes[k], scale=args.scale, seed=1000 + 37 * k, **gene_kw) for k in (0, 1)]
+    half = n // 2
+    ra = synth.make_reads(base_sets[0], half, read_len=L, mix=args.mix, seed=seed, device=str(dev))
+    rb = synth.make_reads(base_sets[1], n - half, read_len=L, mix=args.mix, seed=seed + 1, device=str(dev))
+    bases = torch.cat([ra.bases, rb.bases])
+    offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
+    del ra, rb
+    groups = {}
+    if world > 1 and n_csv < world:  # shared CSVs: one process group per CSV (created collectively, in order)
+        inner = world // n_csv
+        for k in range(n_csv):
+            g = tuple(range(k * inner, (k + 1) * inner))
+            groups[g] = dist.new_group(list(g))
+    build_ms, map_ms, hit_counts, last = [], [], {}, {}
+
+    def step(record):
+        for j in jobs:
+            gs = sets[j.csv]
+            t0 = time.perf_counter()
+            ix = Indexer.from_gene_slices(gs.seqs, gs.reversed_flags, device=local_rank)
+            ix.make_index()
+            t1 = time.perf_counter()
+            m = j.hi - j.lo
+            counts, matches = ix.map_reads_device(bases, offsets[j.lo:j.hi + 1], L)
+            hits, n_hits = ix.compact_hits_device(counts, matches, m, read_id_base=j.lo, cap=max(m // 8, 4096))
+            if len(j.group) > 1:
+                merged = allgather_hits(hits, n_hits, group=groups[j.group])
+                k = merged.shape[0]
+            else:
+                k = int(n_hits.item())   # (waits for the launches)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if record:
+                build_ms.append(1e3 * (t1 - t0))
+                map_ms.append(1e3 * (t2 - t1))
+                hit_counts[j.csv] = k
+                last[j.csv] = (ix.info()["n_keys"], counts[: min(m, 200_000)].cpu().numpy().copy(),
+                               matches[: min(m, 200_000)].cpu().numpy().copy())
+            ix.close()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    value = n * n_csv * args.steps / elapsed
+    result = {
+        "metric": "150bp_reads_x_csvs_per_s_multi_csv_mode_index_rebuilt_per_csv",
+        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL on one GPU over gloo: not a measurement)",
+        "config": {
+            "workload": "%s: %d resident %d-bp reads (%d pairs), %d fusion CSVs alternating IDX-C / IDX-D gene spans (own "
+                        "seed each), index rebuilt per CSV inside the timed region; value counts a read once per CSV; %s"
+                        % (cfg["name"], n, L, n // 2, n_csv, READS_TEXT),
+            "baseline_config": 4, "reads_resident": n, "n_csv": n_csv, "read_len": L,
+            "csvs_of_rank0": [j.csv for j in jobs],
+            "index_build_ms_rank0": [round(x, 2) for x in build_ms[-len(jobs):]],
+            "map_ms_rank0": [round(x, 2) for x in map_ms[-len(jobs):]],
+            "hits_per_csv_rank0": hit_counts,
+            "parallelism": ("CSV k -> rank k %% %d, every rank maps all reads against its CSVs, no collective" % world)
+                           if n_csv >= world else
+                           ("%d ranks per CSV, reads sharded inside the group, one all-gather per CSV" % (world // n_csv)),
+        },
+    }
+    if rank == 0:
+        tot_build, tot_map = sum(build_ms), sum(map_ms)
+        result["roofline"] = {
+            "bound": "hbm", "kernel": "index rebuild (K1) + mapping pass per CSV",
+            "achieved": algo_bytes_per_read(L) * n * len(jobs) * args.steps / (tot_map * 1e-3) / 1e9 if tot_map else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (algo_bytes_per_read(L) * n * len(jobs) * args.steps / (tot_map * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot_map else None,
+            "frac_definition": "algorithmic bytes of the mapping passes / their host-timed duration (includes compaction and one sync per CSV)",
+            "traffic": None,
+            "share_of_step_in_index_rebuild": tot_build / (tot_build + tot_map) if tot_build + tot_map else None,
+        }
+        if not args.no_parity:
+            from oracle import oracle_py
+            cores = usable_cores()
+            checked = {}
+            for j in jobs[:2]:  # one IDX-C-shaped and one IDX-D-shaped CSV
+                ox = oracle_py.OracleIndexer(sets[j.csv].seqs)
+                nk, gc, gm = last[j.csv]
+                ns = gc.shape[0]
+                b = bases[j.lo * L:(j.lo + ns) * L].cpu().numpy()
+                o = np.arange(ns + 1, dtype=np.int64) * L
+                oc, om = ox.map_reads_packed(b, o, threads=cores)
+                gmv = gm.view(om.dtype).reshape(ns, 2)
+                nz = oc > 0
+                ok = bool((gc.astype(np.int32) == oc).all()) and bool((gmv[nz, 0] == om[nz, 0]).all()) and \
+                    bool((gmv[oc == 2, 1] == om[oc == 2, 1]).all()) and nk == ox.stats()["n_keys"]
+                checked[j.csv] = {"checked_reads": ns, "bit_exact": ok, "reads_with_segments": int(nz.sum())}
+                del ox
+            result["parity"] = checked
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

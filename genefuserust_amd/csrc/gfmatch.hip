@@ -487,30 +487,10 @@ int gf_index_lookup(const gf_index* idx, const uint32_t* kmers, int64_t n, int32
   return GF_OK;
 }
 
-int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
-                        int32_t max_read_len, void* d_counts, void* d_matches, void* stream) {
-  if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
-  if (n == 0) return GF_OK;
-  if (!d_offsets || !d_counts || !d_matches) return fail(GF_ERR_ARG, "null device pointer");
-  if (max_read_len > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "max_read_len exceeds GF_MAX_READ_LEN");
-  DeviceGuard guard(idx->device);
-  hipStream_t st = (hipStream_t)stream;
+// One span of a batch (n <= GF_SPAN_MAX reads): the kernels keep read indices in 32 bits.
+static int map_span_device(const gf_index* idx, const uint8_t* bases, const int64_t* offsets, int64_t n,
+                           int32_t max_read_len, uint8_t* counts, gf_seqmatch* matches, hipStream_t st, bool prof) {
   gf_index* mix = const_cast<gf_index*>(idx);
-  const bool prof = idx->profiling;
-  if (prof) {
-    std::lock_guard<std::mutex> lk(mix->prof_mu);
-    if (!mix->have_events) {
-      GF_HIP(hipEventCreate(&mix->ev0));
-      GF_HIP(hipEventCreate(&mix->ev1));
-      for (auto& e : mix->ev_stage) GF_HIP(hipEventCreate(&e));
-      mix->have_events = true;
-    }
-    GF_HIP(hipEventRecord(mix->ev0, st));
-  }
-  const uint8_t* bases = (const uint8_t*)d_bases;
-  const int64_t* offsets = (const int64_t*)d_offsets;
-  uint8_t* counts = (uint8_t*)d_counts;
-  gf_seqmatch* matches = (gf_seqmatch*)d_matches;
   // persistent grid: enough waves to fill every CU, reads interleaved across waves
   // One launch per read-length class present in the batch (<=256, <=1024, <=4096);
   // each launch skips the reads of the other classes, so short reads always get the
@@ -556,6 +536,56 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
                        n, 1024, 1, counts, matches);
   }
   GF_HIP(hipGetLastError());
+  return GF_OK;
+}
+
+// Reads per span of one gf_map_reads_device call.  The flat pipeline's lists hold read indices
+// as uint32 and its workspace grows with the span (64-112 bytes per read), so a batch larger
+// than this is mapped span by span on the same stream — same results, bounded workspace.
+// GF_SPAN_MAX (environment) lowers it for the tests of the split itself.
+static int64_t span_max_reads() {
+  static const int64_t v = [] {
+    int64_t d = (int64_t)1 << 30;
+    if (const char* e = getenv("GF_SPAN_MAX")) {
+      const long long x = atoll(e);
+      if (x >= 1 && x < d) d = (int64_t)x;
+    }
+    return d;
+  }();
+  return v;
+}
+
+int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
+                        int32_t max_read_len, void* d_counts, void* d_matches, void* stream) {
+  if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
+  if (n == 0) return GF_OK;
+  if (!d_offsets || !d_counts || !d_matches) return fail(GF_ERR_ARG, "null device pointer");
+  if (max_read_len > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "max_read_len exceeds GF_MAX_READ_LEN");
+  DeviceGuard guard(idx->device);
+  hipStream_t st = (hipStream_t)stream;
+  gf_index* mix = const_cast<gf_index*>(idx);
+  const bool prof = idx->profiling;
+  if (prof) {
+    std::lock_guard<std::mutex> lk(mix->prof_mu);
+    if (!mix->have_events) {
+      GF_HIP(hipEventCreate(&mix->ev0));
+      GF_HIP(hipEventCreate(&mix->ev1));
+      for (auto& e : mix->ev_stage) GF_HIP(hipEventCreate(&e));
+      mix->have_events = true;
+    }
+    GF_HIP(hipEventRecord(mix->ev0, st));
+  }
+  const uint8_t* bases = (const uint8_t*)d_bases;
+  const int64_t* offsets = (const int64_t*)d_offsets;
+  uint8_t* counts = (uint8_t*)d_counts;
+  gf_seqmatch* matches = (gf_seqmatch*)d_matches;
+  const int64_t span = span_max_reads();
+  for (int64_t s0 = 0; s0 < n; s0 += span) {
+    const int64_t ns = std::min(span, n - s0);
+    // offsets are absolute positions in `bases`: a span is the same call on a later part of the arrays
+    const int rc = map_span_device(idx, bases, offsets + s0, ns, max_read_len, counts + s0, matches + 2 * s0, st, prof);
+    if (rc != GF_OK) return rc;
+  }
   if (prof) {
     std::lock_guard<std::mutex> lk(mix->prof_mu);
     GF_HIP(hipEventRecord(mix->ev1, st));

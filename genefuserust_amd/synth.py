@@ -42,11 +42,17 @@ class GeneSet:
         return sum(len(s) for s in self.seqs)
 
 
+_LOW_COMPLEXITY_UNITS = (b"A", b"T", b"CA", b"GT", b"GATA", b"AAAG", b"CCG", b"TTAGGG")
+
+
 def make_gene(length: int, seed: int, family: Optional[np.ndarray] = None,
-              repeat_frac: float = 0.02, n_frac: float = 0.001) -> bytes:
+              repeat_frac: float = 0.02, n_frac: float = 0.001, low_complexity_frac: float = 0.0) -> bytes:
     """i.i.d. uniform ACGT, then `repeat_frac` of the gene overwritten by copies of
     300-bp elements of a shared 20-element family (gives 2..5-fold and >=6-fold
-    k-mers), then `n_frac` of the bases set to N."""
+    k-mers), then `low_complexity_frac` of it by poly-A / tandem-repeat stretches of
+    60..400 bases (homopolymers, di-, tri-, tetra- and hexanucleotide units: every window
+    inside one is a >= 6-fold key, and their edges give short-period near-repeats), then
+    `n_frac` of the bases set to N."""
     rng = np.random.default_rng(seed)
     g = _ACGT[rng.integers(0, 4, size=length, dtype=np.int64)].copy()
     if family is not None and length > 600:
@@ -55,14 +61,24 @@ def make_gene(length: int, seed: int, family: Optional[np.ndarray] = None,
             e = family[rng.integers(0, family.shape[0])]
             p = int(rng.integers(0, length - family.shape[1]))
             g[p:p + family.shape[1]] = e
+    if low_complexity_frac > 0 and length > 1000:
+        covered = 0
+        while covered < length * low_complexity_frac:
+            unit = np.frombuffer(_LOW_COMPLEXITY_UNITS[int(rng.integers(0, len(_LOW_COMPLEXITY_UNITS)))], dtype=np.uint8)
+            ln = int(rng.integers(60, 401))
+            p = int(rng.integers(0, length - ln))
+            g[p:p + ln] = np.resize(unit, ln)
+            covered += ln
     n_n = int(length * n_frac)
     if n_n:
         g[rng.integers(0, length, size=n_n)] = ord("N")
     return g.tobytes()
 
 
-def make_geneset(shape: str = "IDX-D", scale: float = 1.0, seed: int = 1000) -> GeneSet:
-    """`shape` in {IDX-T, IDX-D, IDX-C}; `scale` < 1 shrinks every gene (tests)."""
+def make_geneset(shape: str = "IDX-D", scale: float = 1.0, seed: int = 1000, repeat_frac: float = 0.02,
+                 low_complexity_frac: float = 0.0) -> GeneSet:
+    """`shape` in {IDX-T, IDX-D, IDX-C}; `scale` < 1 shrinks every gene (tests); `repeat_frac` /
+    `low_complexity_frac`: see make_gene (stress of the rare path: more reads survive to the exact kernel)."""
     genes = index_shapes()[shape]
     fam_rng = np.random.default_rng(seed - 1)
     family = _ACGT[fam_rng.integers(0, 4, size=(20, 300))]
@@ -70,7 +86,7 @@ def make_geneset(shape: str = "IDX-D", scale: float = 1.0, seed: int = 1000) -> 
     for gi, g in enumerate(genes):
         ln = max(64, int(g["len"] * scale))
         names.append(g["name"])
-        seqs.append(make_gene(ln, seed + gi, family))
+        seqs.append(make_gene(ln, seed + gi, family, repeat_frac=repeat_frac, low_complexity_frac=low_complexity_frac))
         rev.append(bool(g["reversed"]))
     return GeneSet(names, seqs, rev)
 

@@ -40,6 +40,20 @@ def test_edit_distance_three_ways(oracle):
             assert edit_distance(b, a) == want
 
 
+def test_edit_distance_reference_vectors(oracle):
+    """The three pairs with expected distances 0 / 1 / 90 that the reference's own unit test holds
+    (edit_distance.rs:221-261), kept as data in tests/golden/edit_distance_ref_test.json: a pin
+    of gf_edit_distance, of the oracle's restatement and of the independent DP model."""
+    from genefuserust_amd import edit_distance
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "edit_distance_ref_test.json")))
+    assert [c["expect"] for c in fx["cases"]] == [0, 1, 90]
+    for c in fx["cases"]:
+        a, b = c["a"].encode(), c["b"].encode()
+        assert edit_distance(a, b) == c["expect"] == edit_distance(b, a)
+        assert oracle.edit_distance(a, b) == c["expect"]
+        assert M.levenshtein(c["a"], c["b"]) == c["expect"]
+
+
 def _c_tail(fusion_seq, rev, read, mapping):
     from genefuserust_amd import _lib
     L = _lib.lib()
