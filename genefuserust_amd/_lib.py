@@ -34,6 +34,11 @@ class GfHit(C.Structure):
     _fields_ = [("read_id", C.c_int64), ("n", C.c_int32), ("pad", C.c_int32), ("m", GfSeqMatch * 2)]
 
 
+class GfPairHit(C.Structure):
+    _fields_ = [("pair_id", C.c_int64), ("source", C.c_int32), ("flags", C.c_int32), ("read_len", C.c_int32),
+                ("merge_diff", C.c_int32), ("seq_offset", C.c_int64), ("m", GfSeqMatch * 2)]
+
+
 class GfReadMatch(C.Structure):
     _fields_ = [("read_break", C.c_int32), ("gap", C.c_int32), ("left_distance", C.c_int32),
                 ("right_distance", C.c_int32), ("left_position", C.c_int32), ("right_position", C.c_int32),
@@ -56,7 +61,9 @@ class GfIndexInfo(C.Structure):
 SEQMATCH_DTYPE = np.dtype([("seq_start", "<i4"), ("seq_end", "<i4"), ("position", "<i4"),
                            ("contig", "<i2"), ("pad", "<i2")])
 HIT_DTYPE = np.dtype([("read_id", "<i8"), ("n", "<i4"), ("pad", "<i4"), ("m", SEQMATCH_DTYPE, (2,))])
-assert SEQMATCH_DTYPE.itemsize == 16 and HIT_DTYPE.itemsize == 48
+PAIR_HIT_DTYPE = np.dtype([("pair_id", "<i8"), ("source", "<i4"), ("flags", "<i4"), ("read_len", "<i4"),
+                           ("merge_diff", "<i4"), ("seq_offset", "<i8"), ("m", SEQMATCH_DTYPE, (2,))])
+assert SEQMATCH_DTYPE.itemsize == 16 and HIT_DTYPE.itemsize == 48 and PAIR_HIT_DTYPE.itemsize == 64
 
 
 class GfError(RuntimeError):
@@ -139,6 +146,12 @@ def lib() -> C.CDLL:
     L.gf_fast_merge.argtypes = [vp, C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p,
                                 C.POINTER(i32), C.POINTER(i32)]
     L.gf_fast_merge.restype = C.c_int
+    L.gf_index_set_gene_reversed.argtypes = [vp, vp, i32]
+    L.gf_index_set_gene_reversed.restype = C.c_int
+    L.gf_scan_pairs_retry_capacity.argtypes = [i64]
+    L.gf_scan_pairs_retry_capacity.restype = i64
+    L.gf_scan_pairs_device.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, i32, i64, i64, vp, i64, vp, vp, i64, vp, vp]
+    L.gf_scan_pairs_device.restype = C.c_int
     L.gf_edit_distance.argtypes = [C.c_char_p, i64, C.c_char_p, i64]
     L.gf_edit_distance.restype = i64
     L.gf_set_profiling.argtypes = [vp, i32]

@@ -610,6 +610,10 @@ __global__ __launch_bounds__(WAVES * 64) void gf_k_map_reads(GfTable T, const ui
   for (int64_t r = (int64_t)blockIdx.x * WAVES + wib; r < n; r += stride) {
     const int64_t off0 = offsets[r];
     const int64_t len64 = offsets[r + 1] - off0;
+    if (T.skip != nullptr && T.skip[r] > 0) {  // not a candidate of this pass (gf_table.h: skip)
+      if (lane == 0) counts[r] = 0;
+      continue;
+    }
     if (len64 > LCAP) {
       if (mark_too_long && lane == 0) counts[r] = GF_COUNT_TOO_LONG;
       continue;
@@ -684,7 +688,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void gf_k_map_reads_short(GfTable T,
     }
 
     const int64_t len64 = cur_end - cur_off;
-    if (len64 > LCAP) {
+    if (T.skip != nullptr && T.skip[r] > 0) {  // not a candidate of this pass (gf_table.h: skip)
+      if (lane == 0) counts[r] = 0;
+    } else if (len64 > LCAP) {
       if (mark_too_long && lane == 0) counts[r] = GF_COUNT_TOO_LONG;
     } else if (len64 < GF_KMER) {
       if (lane == 0) counts[r] = 0;

@@ -1,0 +1,392 @@
+// The pair policy of PairEndScanner::scan_pair_end (src/core/pescanner.rs:427-518) for a whole pack
+// of pairs, resident in HBM from the FASTQ records to the hit list:
+//
+//   merged = pair.fast_merge()                         gf_k_merge_find_stream / gf_k_merge_write
+//   merged?  search the merged read only               one mapping pass over the merged slots
+//   else     search R1, then R2                        one pass each over R1 / R2 in place, the
+//                                                      pairs that merged skipped (GfTable::skip)
+//   a read that mapped to two places (`mapable`, fusion_mapper.rs:107-115) in the wrong
+//   direction (:118-123) is searched again as its reverse complement    gf_k_pair_classify,
+//                                                      gf_k_pair_retry_write, a fourth (small) pass
+//   matches are pushed per pair in the order merged | R1, R2            gf_k_pair_final_*
+//
+// Nothing goes back to the host in between: the kernels below select the candidates, build the
+// reverse complements, and compact the matched reads (records + their bases and qualities, which
+// the host-side tail FusionMapper::make_match / calc_distance needs) in the reference's push order,
+// deterministically (two-level exclusive scans, no atomics).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/gfmatch.h"
+#include "gf_compact_kernels.h"
+
+#define GF_PTILE 1024  // pairs per tile
+#define GF_PPER (GF_PTILE / GF_CTHREADS)
+
+#define GF_PS_NONE 0u
+#define GF_PS_FWD 1u    // two segments in the required direction: a match on the read as it is
+#define GF_PS_RETRY 2u  // two segments, wrong direction: its reverse complement is searched
+
+struct GfPairIn {
+  const uint8_t *l_bases, *l_quals, *r_bases, *r_quals;
+  const int64_t *l_off, *r_off;
+  const uint8_t *m_bases, *m_quals;  // merged reads, back to back
+  const int64_t* m_off;              // int64[n+1]: an empty slot for a pair that did not merge
+  const int32_t* m_len;              // 0 = not merged
+  const int32_t* m_diff;
+  const uint8_t *cM, *c1, *c2;       // counts of the three mapping passes
+  const gf_seqmatch *mM, *m1, *m2;
+  const uint8_t* gene_reversed;      // Fusion::is_reversed() per gene; null = all false
+  int32_t n_genes;
+};
+
+// Indexer::in_required_direction (indexer.rs:541-608) for a two-segment mapping
+__device__ __forceinline__ bool gf_dev_required_direction(const gf_seqmatch& a, const gf_seqmatch& b,
+                                                          const uint8_t* __restrict__ rev, int n_genes) {
+  const bool swap = a.seq_start > b.seq_start;
+  const gf_seqmatch& left = swap ? b : a;
+  const gf_seqmatch& right = swap ? a : b;
+  if (left.position > 0 && right.position > 0) return true;
+  if (left.position < 0 && right.position < 0) return false;
+  const bool lrev = rev && left.contig >= 0 && left.contig < n_genes && rev[left.contig] != 0;
+  const bool rrev = rev && right.contig >= 0 && right.contig < n_genes && rev[right.contig] != 0;
+  if (lrev && !rrev) return false;
+  if (!lrev && rrev) return true;
+  if (left.contig < right.contig) return true;
+  return false;  // (the reference's same-contig test compares left with itself, :598: never true)
+}
+
+// candidate s of pair p: 0 = merged read, 1 = R1, 2 = R2
+__device__ __forceinline__ void gf_pair_candidate(const GfPairIn& P, int64_t p, int s, const uint8_t*& bases,
+                                                  const uint8_t*& quals, int32_t& len, uint8_t& cnt,
+                                                  const gf_seqmatch*& m) {
+  if (s == 0) {
+    const int64_t o = P.m_off[p];
+    bases = P.m_bases + o; quals = P.m_quals + o; len = P.m_len[p]; cnt = P.cM[p]; m = P.mM + 2 * p;
+  } else if (s == 1) {
+    const int64_t o = P.l_off[p];
+    bases = P.l_bases + o; quals = P.l_quals + o; len = (int32_t)(P.l_off[p + 1] - o); cnt = P.c1[p]; m = P.m1 + 2 * p;
+  } else {
+    const int64_t o = P.r_off[p];
+    bases = P.r_bases + o; quals = P.r_quals + o; len = (int32_t)(P.r_off[p + 1] - o); cnt = P.c2[p]; m = P.m2 + 2 * p;
+  }
+}
+
+__device__ __forceinline__ uint32_t gf_pair_status(const GfPairIn& P, int64_t p, int s, int32_t& len) {
+  const uint8_t* b; const uint8_t* q; uint8_t cnt; const gf_seqmatch* m;
+  gf_pair_candidate(P, p, s, b, q, len, cnt, m);
+  if (cnt != 2) return GF_PS_NONE;  // mapping.len() < 2: not mapable (fusion_mapper.rs:107-115)
+  return gf_dev_required_direction(m[0], m[1], P.gene_reversed, P.n_genes) ? GF_PS_FWD : GF_PS_RETRY;
+}
+
+// block-wide exclusive scan of two values at once (256 threads)
+__device__ __forceinline__ void gf_block_scan2(int a, long long b, int* s_a, long long* s_b, int& ea, long long& eb,
+                                               int& ta, long long& tb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int xa = a;
+  long long xb = b;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int ya = __shfl_up(xa, o);
+    const long long yb = __shfl_up(xb, o);
+    if (lane >= o) { xa += ya; xb += yb; }
+  }
+  if (lane == 63) { s_a[wave] = xa; s_b[wave] = xb; }
+  __syncthreads();
+  int ba = 0; long long bb = 0;
+  ta = 0; tb = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) { ba += s_a[w]; bb += s_b[w]; }
+    ta += s_a[w]; tb += s_b[w];
+  }
+  ea = ba + xa - a;
+  eb = bb + xb - b;
+  __syncthreads();
+}
+
+// exclusive prefix sum of int32 lengths into int64 offsets[n+1] (the merged reads' slots): tile sums ...
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_len_tile_sums(const int32_t* __restrict__ len, int64_t n,
+                                                                  uint32_t* __restrict__ tile_sums) {
+  __shared__ int s_wave[4];
+  const int64_t r0 = (int64_t)blockIdx.x * GF_CTILE + (int64_t)threadIdx.x * GF_CPER;
+  int c = 0;
+  for (int k = 0; k < GF_CPER; ++k)
+    if (r0 + k < n) c += len[r0 + k] > 0 ? len[r0 + k] : 0;
+  int total;
+  gf_block_exclusive_scan(c, s_wave, &total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = (uint32_t)total;
+}
+// ... and the offsets (after gf_k_compact_scan of the tile sums)
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_len_offsets(const int32_t* __restrict__ len, int64_t n,
+                                                                const int64_t* __restrict__ tile_offsets,
+                                                                const int64_t* __restrict__ d_total,
+                                                                int64_t* __restrict__ offsets) {
+  __shared__ int s_wave[4];
+  const int64_t r0 = (int64_t)blockIdx.x * GF_CTILE + (int64_t)threadIdx.x * GF_CPER;
+  int c = 0;
+  for (int k = 0; k < GF_CPER; ++k)
+    if (r0 + k < n) c += len[r0 + k] > 0 ? len[r0 + k] : 0;
+  int total;
+  int64_t pos = tile_offsets[blockIdx.x] + gf_block_exclusive_scan(c, s_wave, &total);
+  for (int k = 0; k < GF_CPER; ++k) {
+    const int64_t r = r0 + k;
+    if (r >= n) break;
+    offsets[r] = pos;
+    pos += len[r] > 0 ? len[r] : 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = *d_total;
+}
+
+// ---- classify: which candidates matched as they are, which are searched again reversed ----
+// tile_rc / tile_rb: retries (reads / bytes) per tile.
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_classify(GfPairIn P, int64_t n, uint8_t* __restrict__ st,
+                                                                  uint32_t* __restrict__ tile_rc,
+                                                                  uint32_t* __restrict__ tile_rb,
+                                                                  unsigned long long* __restrict__ n_merged) {
+  __shared__ int s_a[4];
+  __shared__ long long s_b[4];
+  const int64_t p0 = (int64_t)blockIdx.x * GF_PTILE + (int64_t)threadIdx.x * GF_PPER;
+  int rc = 0, merged = 0;
+  long long rb = 0;
+  for (int k = 0; k < GF_PPER; ++k) {
+    const int64_t p = p0 + k;
+    if (p >= n) break;
+    const bool is_merged = P.m_len[p] > 0;
+    merged += is_merged;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      uint32_t v = GF_PS_NONE;
+      int32_t len = 0;
+      if (is_merged ? s == 0 : s != 0) v = gf_pair_status(P, p, s, len);
+      st[3 * p + s] = (uint8_t)v;
+      if (v == GF_PS_RETRY) { rc += 1; rb += len; }
+    }
+  }
+  int ea, ta; long long eb, tb;
+  gf_block_scan2(rc, rb, s_a, s_b, ea, eb, ta, tb);
+  if (threadIdx.x == 0) {
+    tile_rc[blockIdx.x] = (uint32_t)ta;
+    tile_rb[blockIdx.x] = (uint32_t)tb;
+  }
+  // merged pairs, for the totals
+  const uint64_t any = __ballot(merged != 0);
+  if (any) {
+    int msum = merged;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) msum += __shfl_down(msum, o);
+    if ((threadIdx.x & 63) == 0 && msum) atomicAdd(n_merged, (unsigned long long)msum);
+  }
+}
+
+// reverse complement of a read as SequenceRead::reverse_complement builds it (read.rs:243-261 over
+// sequence.rs:22-60): bases complemented to UPPER case, anything but ACGTacgt -> N, qualities reversed
+__device__ __forceinline__ uint8_t gf_complement_base(uint8_t c) {
+  switch (c) {
+    case 'A': case 'a': return 'T';
+    case 'T': case 't': return 'A';
+    case 'C': case 'c': return 'G';
+    case 'G': case 'g': return 'C';
+    default: return 'N';
+  }
+}
+
+// ---- retry_write: the reverse complements of the retried reads, back to back, in candidate order ----
+// slot_of[3p+s] = index of the candidate in the retry batch.  Retries beyond the capacities are
+// dropped and reported (totals: overflow), never half-written.
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_retry_write(
+    GfPairIn P, int64_t n, const uint8_t* __restrict__ st, const int64_t* __restrict__ tile_off_rc,
+    const int64_t* __restrict__ tile_off_rb, int64_t cap_reads, int64_t cap_bytes, int64_t* __restrict__ r_off,
+    uint8_t* __restrict__ r_bases, uint8_t* __restrict__ r_quals, int32_t* __restrict__ slot_of) {
+  __shared__ int s_a[4];
+  __shared__ long long s_b[4];
+  const int64_t p0 = (int64_t)blockIdx.x * GF_PTILE + (int64_t)threadIdx.x * GF_PPER;
+  int rc = 0;
+  long long rb = 0;
+  for (int k = 0; k < GF_PPER; ++k) {
+    const int64_t p = p0 + k;
+    if (p >= n) break;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (st[3 * p + s] == GF_PS_RETRY) {
+        const uint8_t* b; const uint8_t* q; int32_t len; uint8_t cnt; const gf_seqmatch* m;
+        gf_pair_candidate(P, p, s, b, q, len, cnt, m);
+        rc += 1;
+        rb += len;
+      }
+  }
+  int ea, ta; long long eb, tb;
+  gf_block_scan2(rc, rb, s_a, s_b, ea, eb, ta, tb);
+  if (!rc) return;
+  int64_t k_out = tile_off_rc[blockIdx.x] + ea;
+  int64_t b_out = tile_off_rb[blockIdx.x] + eb;
+  for (int k = 0; k < GF_PPER; ++k) {
+    const int64_t p = p0 + k;
+    if (p >= n) break;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (st[3 * p + s] != GF_PS_RETRY) continue;
+      const uint8_t* b; const uint8_t* q; int32_t len; uint8_t cnt; const gf_seqmatch* m;
+      gf_pair_candidate(P, p, s, b, q, len, cnt, m);
+      const bool fits = k_out < cap_reads && b_out + len <= cap_bytes;
+      slot_of[3 * p + s] = fits ? (int32_t)k_out : -1;
+      if (fits) {
+        r_off[k_out] = b_out;
+        for (int j = 0; j < len; ++j) {
+          r_bases[b_out + j] = gf_complement_base(b[len - 1 - j]);
+          r_quals[b_out + j] = q[len - 1 - j];
+        }
+      }
+      k_out += 1;
+      b_out += len;
+    }
+  }
+}
+
+// offsets of the unused slots of the retry batch (empty reads at the end of the buffer), and the
+// overflow flag.  totals: [0] hits, [1] hit bytes, [2] merged pairs, [3] retried reads, [4] overflow bits
+__global__ void gf_k_pair_retry_tail(const int64_t* __restrict__ d_n_retry, const int64_t* __restrict__ d_retry_bytes,
+                                     int64_t cap_reads, int64_t cap_bytes, int64_t* __restrict__ r_off,
+                                     int64_t* __restrict__ totals) {
+  const int64_t nr = *d_n_retry, nb = *d_retry_bytes;
+  // Over capacity: the whole retry batch is emptied (every offset 0) and the flag raised — the caller
+  // runs the pack again with room for all (gf_scan_pairs_device: totals[4]); a partly searched batch
+  // would look like a result.
+  const bool over = nr > cap_reads || nb > cap_bytes;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= cap_reads; k += (int64_t)gridDim.x * blockDim.x) {
+    if (over) r_off[k] = 0;
+    else if (k >= nr) r_off[k] = nb;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    totals[3] = nr;
+    if (over) totals[4] |= 1;
+  }
+}
+
+// ---- final: the matches of the pack, in the reference's push order ----
+__device__ __forceinline__ bool gf_pair_final(const GfPairIn& P, int64_t p, int s, const uint8_t* __restrict__ st,
+                                              const int32_t* __restrict__ slot_of, const uint8_t* __restrict__ cR,
+                                              const gf_seqmatch* __restrict__ mR, int& rc_slot) {
+  const uint8_t v = st[3 * p + s];
+  rc_slot = -1;
+  if (v == GF_PS_FWD) return true;
+  if (v != GF_PS_RETRY) return false;
+  const int32_t k = slot_of[3 * p + s];
+  if (k < 0 || cR[k] != 2) return false;
+  if (!gf_dev_required_direction(mR[2 * (int64_t)k], mR[2 * (int64_t)k + 1], P.gene_reversed, P.n_genes)) return false;
+  rc_slot = k;
+  return true;
+}
+
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_final_count(
+    GfPairIn P, int64_t n, const uint8_t* __restrict__ st, const int32_t* __restrict__ slot_of,
+    const uint8_t* __restrict__ cR, const gf_seqmatch* __restrict__ mR, uint32_t* __restrict__ tile_hc,
+    uint32_t* __restrict__ tile_hb) {
+  __shared__ int s_a[4];
+  __shared__ long long s_b[4];
+  const int64_t p0 = (int64_t)blockIdx.x * GF_PTILE + (int64_t)threadIdx.x * GF_PPER;
+  int hc = 0;
+  long long hb = 0;
+  for (int k = 0; k < GF_PPER; ++k) {
+    const int64_t p = p0 + k;
+    if (p >= n) break;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (st[3 * p + s] == GF_PS_NONE) continue;
+      int slot;
+      if (gf_pair_final(P, p, s, st, slot_of, cR, mR, slot)) {
+        const uint8_t* b; const uint8_t* q; int32_t len; uint8_t cnt; const gf_seqmatch* m;
+        gf_pair_candidate(P, p, s, b, q, len, cnt, m);
+        hc += 1;
+        hb += len;
+      }
+    }
+  }
+  int ea, ta; long long eb, tb;
+  gf_block_scan2(hc, hb, s_a, s_b, ea, eb, ta, tb);
+  if (threadIdx.x == 0) {
+    tile_hc[blockIdx.x] = (uint32_t)ta;
+    tile_hb[blockIdx.x] = (uint32_t)tb;
+  }
+}
+
+__global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_final_write(
+    GfPairIn P, int64_t n, int64_t pair_id_base, const uint8_t* __restrict__ st, const int32_t* __restrict__ slot_of,
+    const uint8_t* __restrict__ cR, const gf_seqmatch* __restrict__ mR, const int64_t* __restrict__ r_off,
+    const uint8_t* __restrict__ r_bases, const uint8_t* __restrict__ r_quals, const int64_t* __restrict__ tile_off_hc,
+    const int64_t* __restrict__ tile_off_hb, gf_pair_hit* __restrict__ hits, int64_t hits_cap,
+    uint8_t* __restrict__ out_bases, uint8_t* __restrict__ out_quals, int64_t bytes_cap) {
+  __shared__ int s_a[4];
+  __shared__ long long s_b[4];
+  const int64_t p0 = (int64_t)blockIdx.x * GF_PTILE + (int64_t)threadIdx.x * GF_PPER;
+  int hc = 0;
+  long long hb = 0;
+  for (int k = 0; k < GF_PPER; ++k) {
+    const int64_t p = p0 + k;
+    if (p >= n) break;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (st[3 * p + s] == GF_PS_NONE) continue;
+      int slot;
+      if (gf_pair_final(P, p, s, st, slot_of, cR, mR, slot)) {
+        const uint8_t* b; const uint8_t* q; int32_t len; uint8_t cnt; const gf_seqmatch* m;
+        gf_pair_candidate(P, p, s, b, q, len, cnt, m);
+        hc += 1;
+        hb += len;
+      }
+    }
+  }
+  int ea, ta; long long eb, tb;
+  gf_block_scan2(hc, hb, s_a, s_b, ea, eb, ta, tb);
+  if (!hc) return;
+  int64_t k_out = tile_off_hc[blockIdx.x] + ea;
+  int64_t b_out = tile_off_hb[blockIdx.x] + eb;
+  for (int k = 0; k < GF_PPER; ++k) {
+    const int64_t p = p0 + k;
+    if (p >= n) break;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (st[3 * p + s] == GF_PS_NONE) continue;
+      int slot;
+      if (!gf_pair_final(P, p, s, st, slot_of, cR, mR, slot)) continue;
+      const uint8_t* b; const uint8_t* q; int32_t len; uint8_t cnt; const gf_seqmatch* m;
+      gf_pair_candidate(P, p, s, b, q, len, cnt, m);
+      if (slot >= 0) {  // the match is on the reverse complement: its bases, its mapping
+        b = r_bases + r_off[slot];
+        q = r_quals + r_off[slot];
+        m = mR + 2 * (int64_t)slot;
+      }
+      if (k_out < hits_cap) {
+        gf_pair_hit h;
+        h.pair_id = pair_id_base + p;
+        h.source = s;
+        // bit 0: found on the reverse complement; bit 1: ReadMatch.m_reversed as the reference sets it —
+        // for R1 / R2 (pescanner.rs:489,:511), not for a merged read (:465-468)
+        h.flags = (slot >= 0 ? 1 : 0) | ((slot >= 0 && s != 0) ? 2 : 0);
+        h.read_len = len;
+        h.merge_diff = s == 0 ? P.m_diff[p] : 0;
+        h.seq_offset = b_out;
+        h.m[0] = m[0];
+        h.m[1] = m[1];
+        hits[k_out] = h;
+      }
+      if (b_out + len <= bytes_cap)
+        for (int j = 0; j < len; ++j) {
+          out_bases[b_out + j] = b[j];
+          out_quals[b_out + j] = q[j];
+        }
+      k_out += 1;
+      b_out += len;
+    }
+  }
+}
+
+__global__ void gf_k_pair_totals(const int64_t* __restrict__ d_hits, const int64_t* __restrict__ d_hit_bytes,
+                                 const unsigned long long* __restrict__ n_merged, int64_t hits_cap, int64_t bytes_cap,
+                                 int64_t* __restrict__ totals) {
+  totals[0] = *d_hits;
+  totals[1] = *d_hit_bytes;
+  totals[2] = (int64_t)*n_merged;
+  if (*d_hits > hits_cap || *d_hit_bytes > bytes_cap) totals[4] |= 2;
+}

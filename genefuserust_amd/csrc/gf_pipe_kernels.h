@@ -297,7 +297,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       if (in_range) {
 #endif
         const int64_t len64 = off1 - off0;
-        if (len64 > batch_max) {
+        if (T.skip != nullptr && T.skip[r] > 0) {
+          counts[r] = 0;  // not a candidate of this pass (gf_table.h: skip)
+        } else if (len64 > batch_max) {
           counts[r] = GF_COUNT_TOO_LONG;
         } else if (len64 > lmax) {
           long1k = len64 <= 1024;

@@ -83,6 +83,10 @@ struct GfTable {
                             //     seed+verify runs the filter pass for reads without a candidate itself
   uint32_t nbuckets;
   int32_t n_genes;
+  // per-call, optional: read r is not searched (its result is []) when skip[r] > 0.  The pair
+  // pipeline maps R1 / R2 in place and skips the pairs whose merged read is searched instead
+  // (pescanner.rs:446-471): skip = the merged lengths.
+  const int32_t* skip;
 };
 
 // filter word and bit pair of a 14-mer x (28 bits).  One multiplicative hash: the word comes

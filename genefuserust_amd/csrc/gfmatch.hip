@@ -22,10 +22,12 @@
 #include "gf_merge_kernels.h"
 #include "gf_fastq_kernels.h"
 #include "gf_pipe_kernels.h"
+#include "gf_pair_kernels.h"
 #include "gf_table.h"
 
 static_assert(sizeof(gf_seqmatch) == 16, "gf_seqmatch layout");
 static_assert(sizeof(gf_hit) == 48, "gf_hit layout");
+static_assert(sizeof(gf_pair_hit) == 64, "gf_pair_hit layout");
 static_assert(GF_LIN_PAD >= GF_MAX_READ_LEN, "site-code padding must cover the longest read");
 
 namespace {
@@ -107,6 +109,10 @@ struct gf_index {
   struct Workspace { void* base = nullptr; size_t bytes = 0; };
   std::map<hipStream_t, Workspace> ws;
   std::mutex ws_mu;
+  // the pair pipeline's own per-stream workspace (gf_scan_pairs_device), same rules
+  std::map<hipStream_t, Workspace> ws_pair;
+  std::mutex pair_mu;
+  uint8_t* d_gene_rev = nullptr;  // Fusion::is_reversed() per gene (gf_index_set_gene_reversed)
   // device arena of the host-buffer entry points (gf_map_reads, gf_map_reads_hits), grow-only
   void* stage_base = nullptr;
   size_t stage_bytes = 0;
@@ -126,6 +132,9 @@ struct gf_index {
     if (d_bloom) (void)hipFree(d_bloom);
     for (auto& kv : ws)
       if (kv.second.base) (void)hipFree(kv.second.base);
+    for (auto& kv : ws_pair)
+      if (kv.second.base) (void)hipFree(kv.second.base);
+    if (d_gene_rev) (void)hipFree(d_gene_rev);
     if (stage_base) (void)hipFree(stage_base);
     if (have_events) {
       (void)hipEventDestroy(ev0);
@@ -135,8 +144,8 @@ struct gf_index {
   }
 };
 
-static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** out) {
-  gf_index::Workspace& W = mix->ws[st];  // caller holds ws_mu
+static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** out, bool pair = false) {
+  gf_index::Workspace& W = pair ? mix->ws_pair[st] : mix->ws[st];  // caller holds ws_mu / pair_mu
   if (W.bytes < need) {
     if (W.base) {
       GF_HIP(hipStreamSynchronize(st));  // earlier calls on this stream may still use it
@@ -197,8 +206,8 @@ static FlatWs flat_carve(uint8_t* wp, const FlatPlan& p) {
 // batch_max = the caller's limit: reads in between go to the wave-per-read kernels of the
 // longer classes (LDS footprints for 1024 and 4096 bases) through a list.
 template <int PW>
-static int launch_flat(const gf_index* idx, hipStream_t st, const uint8_t* bases, const int64_t* offsets, int64_t n,
-                       int lmax, int batch_max, uint8_t* counts, gf_seqmatch* matches, const FlatWs& w,
+static int launch_flat(const gf_index* idx, const GfTable& T, hipStream_t st, const uint8_t* bases, const int64_t* offsets,
+                       int64_t n, int lmax, int batch_max, uint8_t* counts, gf_seqmatch* matches, const FlatWs& w,
                        const FlatPlan& p, hipEvent_t* ev) {
   GF_HIP(hipMemsetAsync(w.ctr, 0, 64, st));
   if (ev) GF_HIP(hipEventRecord(ev[0], st));
@@ -206,37 +215,37 @@ static int launch_flat(const gf_index* idx, hipStream_t st, const uint8_t* bases
   // per CU (40 KB of LDS each, padded with dynamic LDS) measured 2.5 % faster than six.
   size_t pad_lds = PW == 10 ? 24000 : 0;
   if (const char* e = getenv("GF_SV_PAD_LDS")) pad_lds = (size_t)atoi(e);  // experiments
-  hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(p.nblk), dim3(256), pad_lds, st, idx->table, bases, offsets, n,
+  hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(p.nblk), dim3(256), pad_lds, st, T, bases, offsets, n,
                      lmax, batch_max, counts, (GfPipeEntryW<PW>*)w.list_b, w.blk_cnt, p.per_block, w.list_long, w.ctr);
   if (ev) GF_HIP(hipEventRecord(ev[1], st));
   // a filter that does not fit an XCD's L2 (bloom_in_l2 == 1) is asked part by part, so that the part
   // in use stays there (gf_k_probe_filter); GF_FILTER_PARTS sets the number of parts (experiments)
   static const int parts_env = getenv("GF_FILTER_PARTS") ? atoi(getenv("GF_FILTER_PARTS")) : 0;
-  int nparts = idx->table.bloom_in_l2 == 1 ? 2 : 1;
-  if (parts_env >= 1 && parts_env <= 8 && idx->table.bloom_in_l2 == 1) nparts = parts_env;
+  int nparts = T.bloom_in_l2 == 1 ? 2 : 1;
+  if (parts_env >= 1 && parts_env <= 8 && T.bloom_in_l2 == 1) nparts = parts_env;
   unsigned int *cnt_in = w.blk_cnt, *cnt_out = w.blk_cnt2;
   for (int ph = 0; ph < nparts; ++ph) {
-    hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(p.nblk), dim3(256), 0, st, idx->table,
+    hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(p.nblk), dim3(256), 0, st, T,
                        (GfPipeEntryW<PW>*)w.list_b, (const unsigned int*)cnt_in, p.per_block, counts, cnt_out, ph,
                        nparts);
     std::swap(cnt_in, cnt_out);
   }
   const unsigned int* survivors = cnt_in;  // (the last launch's output)
   if (ev) GF_HIP(hipEventRecord(ev[2], st));
-  hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(p.nblk), dim3(256), 0, st, idx->table,
+  hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(p.nblk), dim3(256), 0, st, T,
                      (const GfPipeEntryW<PW>*)w.list_b, survivors, p.per_block, counts, w.list_c, w.ctr);
   if (ev) GF_HIP(hipEventRecord(ev[3], st));
   if (PW <= 16)
-    hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(idx->n_cus * 8), dim3(256), 0, st, idx->table, bases, offsets,
+    hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(idx->n_cus * 8), dim3(256), 0, st, T, bases, offsets,
                        w.list_c, (int64_t)1, w.ctr + 1, counts, matches);
   else  // survivors of up to 320 bases
-    hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4>), dim3(idx->n_cus * 4), dim3(256), 0, st, idx->table, bases,
+    hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4>), dim3(idx->n_cus * 4), dim3(256), 0, st, T, bases,
                        offsets, w.list_c, (int64_t)1, w.ctr + 1, counts, matches);
   if (batch_max > lmax) {
-    hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4>), dim3(idx->n_cus * 4), dim3(256), 0, st, idx->table, bases,
+    hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4>), dim3(idx->n_cus * 4), dim3(256), 0, st, T, bases,
                        offsets, w.list_long, (int64_t)1, w.ctr + 2, counts, matches);
     if (batch_max > 1024)
-      hipLaunchKernelGGL((gf_k_map_reads_list<4096, 2>), dim3(idx->n_cus * 4), dim3(128), 0, st, idx->table, bases,
+      hipLaunchKernelGGL((gf_k_map_reads_list<4096, 2>), dim3(idx->n_cus * 4), dim3(128), 0, st, T, bases,
                          offsets, w.list_long + (n - 1), (int64_t)-1, w.ctr + 3, counts, matches);
   }
   GF_HIP(hipGetLastError());
@@ -489,8 +498,11 @@ int gf_index_lookup(const gf_index* idx, const uint32_t* kmers, int64_t n, int32
 
 // One span of a batch (n <= GF_SPAN_MAX reads): the kernels keep read indices in 32 bits.
 static int map_span_device(const gf_index* idx, const uint8_t* bases, const int64_t* offsets, int64_t n,
-                           int32_t max_read_len, uint8_t* counts, gf_seqmatch* matches, hipStream_t st, bool prof) {
+                           int32_t max_read_len, uint8_t* counts, gf_seqmatch* matches, hipStream_t st, bool prof,
+                           const int32_t* skip) {
   gf_index* mix = const_cast<gf_index*>(idx);
+  GfTable T = idx->table;
+  T.skip = skip;  // (per call: the index itself stays read-only)
   // persistent grid: enough waves to fill every CU, reads interleaved across waves
   // One launch per read-length class present in the batch (<=256, <=1024, <=4096);
   // each launch skips the reads of the other classes, so short reads always get the
@@ -508,31 +520,31 @@ static int map_span_device(const gf_index* idx, const uint8_t* bases, const int6
     if (wrc != GF_OK) return wrc;
     const FlatWs w = flat_carve((uint8_t*)ws_base, p);
     hipEvent_t* ev = prof ? mix->ev_stage : nullptr;
-    wrc = pw == 10   ? launch_flat<10>(idx, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
-          : pw == 16 ? launch_flat<16>(idx, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
-                     : launch_flat<20>(idx, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev);
+    wrc = pw == 10   ? launch_flat<10>(idx, T, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
+          : pw == 16 ? launch_flat<16>(idx, T, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
+                     : launch_flat<20>(idx, T, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev);
     if (wrc != GF_OK) return wrc;
     if (prof) mix->stages_recorded = true;
   } else {
     constexpr int W = 4;
     int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 8);
     if (idx->map_variant == 1)
-      hipLaunchKernelGGL((gf_k_map_reads_short<W, 0>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
+      hipLaunchKernelGGL((gf_k_map_reads_short<W, 0>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
                          n, top == 0 ? 1 : 0, counts, matches);
     else
-      hipLaunchKernelGGL((gf_k_map_reads_short<W, 1>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
+      hipLaunchKernelGGL((gf_k_map_reads_short<W, 1>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
                          n, top == 0 ? 1 : 0, counts, matches);
   }
   if (top >= 1 && idx->map_variant != 0) {
     constexpr int W = 4;
     int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 4 * 2);
-    hipLaunchKernelGGL((gf_k_map_reads<1024, W, 0>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
+    hipLaunchKernelGGL((gf_k_map_reads<1024, W, 0>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
                        n, 256, top == 1 ? 1 : 0, counts, matches);
   }
   if (top >= 2 && idx->map_variant != 0) {
     constexpr int W = 2;
     int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 2 * 2);
-    hipLaunchKernelGGL((gf_k_map_reads<4096, W, 0>), dim3(grid), dim3(W * 64), 0, st, idx->table, bases, offsets,
+    hipLaunchKernelGGL((gf_k_map_reads<4096, W, 0>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
                        n, 1024, 1, counts, matches);
   }
   GF_HIP(hipGetLastError());
@@ -555,8 +567,9 @@ static int64_t span_max_reads() {
   return v;
 }
 
-int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
-                        int32_t max_read_len, void* d_counts, void* d_matches, void* stream) {
+static int map_reads_device_impl(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
+                                 int32_t max_read_len, void* d_counts, void* d_matches, void* stream,
+                                 const int32_t* d_skip) {
   if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
   if (n == 0) return GF_OK;
   if (!d_offsets || !d_counts || !d_matches) return fail(GF_ERR_ARG, "null device pointer");
@@ -583,7 +596,8 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
   for (int64_t s0 = 0; s0 < n; s0 += span) {
     const int64_t ns = std::min(span, n - s0);
     // offsets are absolute positions in `bases`: a span is the same call on a later part of the arrays
-    const int rc = map_span_device(idx, bases, offsets + s0, ns, max_read_len, counts + s0, matches + 2 * s0, st, prof);
+    const int rc = map_span_device(idx, bases, offsets + s0, ns, max_read_len, counts + s0, matches + 2 * s0, st, prof,
+                                   d_skip ? d_skip + s0 : nullptr);
     if (rc != GF_OK) return rc;
   }
   if (prof) {
@@ -592,6 +606,11 @@ int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_
     mix->recorded = true;
   }
   return GF_OK;
+}
+
+int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
+                        int32_t max_read_len, void* d_counts, void* d_matches, void* stream) {
+  return map_reads_device_impl(idx, d_bases, d_offsets, n, max_read_len, d_counts, d_matches, stream, nullptr);
 }
 
 int64_t gf_compact_workspace_bytes(int64_t n) {
@@ -1104,6 +1123,134 @@ int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_by
   hipLaunchKernelGGL(gf_k_fq_gather, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text,
                      (const int64_t*)d_nl_pos, n_newlines, n_bytes, n_records, tile_offsets, (int64_t*)d_offsets,
                      (uint8_t*)d_bases, (uint8_t*)d_quals, cap_bytes, (unsigned long long*)d_n_bad);
+  GF_HIP(hipGetLastError());
+  return GF_OK;
+}
+
+// ---- the pair policy of scan_pair_end for a whole pack, device resident (gf_pair_kernels.h) ----
+int gf_index_set_gene_reversed(gf_index* idx, const uint8_t* gene_reversed, int32_t n_genes) {
+  if (!idx) return fail(GF_ERR_ARG, "null index");
+  if (n_genes != idx->table.n_genes) return fail(GF_ERR_ARG, "n_genes differs from the index");
+  if (n_genes > 0 && !gene_reversed) return fail(GF_ERR_ARG, "null flags");
+  DeviceGuard guard(idx->device);
+  if (!idx->d_gene_rev) GF_HIP(hipMalloc((void**)&idx->d_gene_rev, (size_t)std::max(n_genes, 1)));
+  if (n_genes > 0) GF_HIP(hipMemcpy(idx->d_gene_rev, gene_reversed, (size_t)n_genes, hipMemcpyHostToDevice));
+  return GF_OK;
+}
+
+int64_t gf_scan_pairs_retry_capacity(int64_t n) { return n < 0 ? 0 : std::max<int64_t>(4096, n / 4); }
+
+int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
+                         int64_t l_bytes, const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets,
+                         int64_t r_bytes, int64_t n, int32_t max_read_len, int64_t pair_id_base, int64_t retry_cap,
+                         void* d_hits, int64_t hits_cap, void* d_hit_bases, void* d_hit_quals, int64_t hit_bytes_cap,
+                         void* d_totals, void* stream) {
+  if (!idx || n < 0 || l_bytes < 0 || r_bytes < 0 || hits_cap < 0 || hit_bytes_cap < 0 || max_read_len < 0)
+    return fail(GF_ERR_ARG, "null index or negative size");
+  if (!d_totals) return fail(GF_ERR_ARG, "null totals");
+  if (n > 0 && (!d_l_bases || !d_l_quals || !d_l_offsets || !d_r_bases || !d_r_quals || !d_r_offsets))
+    return fail(GF_ERR_ARG, "null device pointer");
+  if ((hits_cap > 0 && !d_hits) || (hit_bytes_cap > 0 && (!d_hit_bases || !d_hit_quals)))
+    return fail(GF_ERR_ARG, "null output pointer");
+  if (n > (int64_t)0x7FFFFFFF / 3) return fail(GF_ERR_CAPACITY, "more than 2^31 / 3 pairs in one pack");
+  const int64_t merged_max = 2 * (int64_t)max_read_len;  // a merged read is shorter than len1 + len2
+  if (merged_max > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "2 * max_read_len exceeds GF_MAX_READ_LEN");
+  DeviceGuard guard(idx->device);
+  hipStream_t st = (hipStream_t)stream;
+  gf_index* mix = const_cast<gf_index*>(idx);
+  GF_HIP(hipMemsetAsync(d_totals, 0, 8 * sizeof(int64_t), st));
+  if (n == 0) return GF_OK;
+  if (retry_cap <= 0) retry_cap = gf_scan_pairs_retry_capacity(n);
+  retry_cap = std::min<int64_t>(retry_cap, 3 * n);
+  const int64_t retry_bytes_cap = std::min<int64_t>(retry_cap * merged_max, l_bytes + r_bytes + 64);
+  const int64_t ntiles = (n + GF_PTILE - 1) / GF_PTILE;
+  const int64_t nctiles = (n + GF_CTILE - 1) / GF_CTILE;
+
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  struct Carve {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+  } cv;
+  (void)al;
+  const size_t o_mlen = cv.take((size_t)n * 4), o_mdiff = cv.take((size_t)n * 4), o_moff = cv.take(((size_t)n + 1) * 8);
+  const size_t o_mb = cv.take((size_t)(l_bytes + r_bytes) + 64), o_mq = cv.take((size_t)(l_bytes + r_bytes) + 64);
+  const size_t o_cM = cv.take((size_t)n), o_c1 = cv.take((size_t)n), o_c2 = cv.take((size_t)n);
+  const size_t o_mM = cv.take((size_t)n * 32), o_m1 = cv.take((size_t)n * 32), o_m2 = cv.take((size_t)n * 32);
+  const size_t o_st = cv.take((size_t)n * 3), o_slot = cv.take((size_t)n * 3 * 4);
+  const size_t o_tc = cv.take((size_t)std::max(ntiles, nctiles) * 4 * 2);      // two uint32 per tile
+  const size_t o_to = cv.take((size_t)std::max(ntiles, nctiles) * 8 * 2);      // two int64 per tile
+  const size_t o_scal = cv.take(256);                                          // scalars: totals of the scans, merged pairs
+  const size_t o_roff = cv.take(((size_t)retry_cap + 1) * 8);
+  const size_t o_rb = cv.take((size_t)retry_bytes_cap + 64), o_rq = cv.take((size_t)retry_bytes_cap + 64);
+  const size_t o_cR = cv.take((size_t)retry_cap), o_mR = cv.take((size_t)retry_cap * 32);
+
+  std::lock_guard<std::mutex> lk(mix->pair_mu);  // held until this call's launches are queued
+  void* base = nullptr;
+  int rc = acquire_workspace(mix, st, cv.off, &base, true);
+  if (rc != GF_OK) return rc;
+  uint8_t* wp = (uint8_t*)base;
+  int32_t* m_len = (int32_t*)(wp + o_mlen); int32_t* m_diff = (int32_t*)(wp + o_mdiff); int64_t* m_off = (int64_t*)(wp + o_moff);
+  uint8_t* mb = wp + o_mb; uint8_t* mq = wp + o_mq;
+  uint8_t *cM = wp + o_cM, *c1 = wp + o_c1, *c2 = wp + o_c2;
+  gf_seqmatch *mM = (gf_seqmatch*)(wp + o_mM), *m1 = (gf_seqmatch*)(wp + o_m1), *m2 = (gf_seqmatch*)(wp + o_m2);
+  uint8_t* stt = wp + o_st; int32_t* slot_of = (int32_t*)(wp + o_slot);
+  const int64_t tmax = std::max(ntiles, nctiles);
+  uint32_t *tcA = (uint32_t*)(wp + o_tc), *tcB = tcA + tmax;
+  int64_t *toA = (int64_t*)(wp + o_to), *toB = toA + tmax;
+  int64_t* scal = (int64_t*)(wp + o_scal);  // [0] merged bytes, [1] retries, [2] retry bytes, [3] hits, [4] hit bytes, [5] merged pairs
+  int64_t* r_off = (int64_t*)(wp + o_roff); uint8_t* rb = wp + o_rb; uint8_t* rq = wp + o_rq;
+  uint8_t* cR = wp + o_cR; gf_seqmatch* mR = (gf_seqmatch*)(wp + o_mR);
+  int64_t* totals = (int64_t*)d_totals;
+  GF_HIP(hipMemsetAsync(scal, 0, 256, st));
+
+  // 1. fast_merge: lengths, then the slots of the merged reads (exclusive scan), then the reads
+  rc = gf_fast_merge_find_device(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, max_read_len,
+                                 m_len, m_diff, stream);
+  if (rc != GF_OK) return rc;
+  hipLaunchKernelGGL(gf_k_len_tile_sums, dim3((unsigned)nctiles), dim3(GF_CTHREADS), 0, st, (const int32_t*)m_len, n, tcA);
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcA, nctiles, toA, scal + 0);
+  hipLaunchKernelGGL(gf_k_len_offsets, dim3((unsigned)nctiles), dim3(GF_CTHREADS), 0, st, (const int32_t*)m_len, n,
+                     (const int64_t*)toA, (const int64_t*)(scal + 0), m_off);
+  GF_HIP(hipGetLastError());
+  rc = gf_fast_merge_write_device(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, m_len, m_off,
+                                  mb, mq, stream);
+  if (rc != GF_OK) return rc;
+  // 2. the merged reads; R1 and R2 of the pairs that did not merge (in place, the others skipped)
+  rc = map_reads_device_impl(idx, mb, m_off, n, (int32_t)std::max<int64_t>(merged_max, 1), cM, mM, stream, nullptr);
+  if (rc != GF_OK) return rc;
+  rc = map_reads_device_impl(idx, d_l_bases, d_l_offsets, n, std::max(max_read_len, 1), c1, m1, stream, m_len);
+  if (rc != GF_OK) return rc;
+  rc = map_reads_device_impl(idx, d_r_bases, d_r_offsets, n, std::max(max_read_len, 1), c2, m2, stream, m_len);
+  if (rc != GF_OK) return rc;
+  // 3. matches as they are / reverse-complement retries
+  GfPairIn P;
+  P.l_bases = (const uint8_t*)d_l_bases; P.l_quals = (const uint8_t*)d_l_quals; P.l_off = (const int64_t*)d_l_offsets;
+  P.r_bases = (const uint8_t*)d_r_bases; P.r_quals = (const uint8_t*)d_r_quals; P.r_off = (const int64_t*)d_r_offsets;
+  P.m_bases = mb; P.m_quals = mq; P.m_off = m_off; P.m_len = m_len; P.m_diff = m_diff;
+  P.cM = cM; P.c1 = c1; P.c2 = c2; P.mM = mM; P.m1 = m1; P.m2 = m2;
+  P.gene_reversed = idx->d_gene_rev; P.n_genes = idx->table.n_genes;
+  hipLaunchKernelGGL(gf_k_pair_classify, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, stt, tcA, tcB,
+                     (unsigned long long*)(scal + 5));
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcA, ntiles, toA, scal + 1);
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcB, ntiles, toB, scal + 2);
+  hipLaunchKernelGGL(gf_k_pair_retry_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, (const uint8_t*)stt,
+                     (const int64_t*)toA, (const int64_t*)toB, retry_cap, retry_bytes_cap, r_off, rb, rq, slot_of);
+  hipLaunchKernelGGL(gf_k_pair_retry_tail, dim3((unsigned)std::min<int64_t>((retry_cap + 256) / 256, 1024)), dim3(256), 0, st,
+                     (const int64_t*)(scal + 1), (const int64_t*)(scal + 2), retry_cap, retry_bytes_cap, r_off, totals);
+  GF_HIP(hipGetLastError());
+  rc = map_reads_device_impl(idx, rb, r_off, retry_cap, (int32_t)std::max<int64_t>(merged_max, 1), cR, mR, stream, nullptr);
+  if (rc != GF_OK) return rc;
+  // 4. the matches, in push order, with their reads
+  hipLaunchKernelGGL(gf_k_pair_final_count, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, (const uint8_t*)stt,
+                     (const int32_t*)slot_of, (const uint8_t*)cR, (const gf_seqmatch*)mR, tcA, tcB);
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcA, ntiles, toA, scal + 3);
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcB, ntiles, toB, scal + 4);
+  hipLaunchKernelGGL(gf_k_pair_final_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, pair_id_base,
+                     (const uint8_t*)stt, (const int32_t*)slot_of, (const uint8_t*)cR, (const gf_seqmatch*)mR,
+                     (const int64_t*)r_off, (const uint8_t*)rb, (const uint8_t*)rq, (const int64_t*)toA, (const int64_t*)toB,
+                     (gf_pair_hit*)d_hits, hits_cap, (uint8_t*)d_hit_bases, (uint8_t*)d_hit_quals, hit_bytes_cap);
+  hipLaunchKernelGGL(gf_k_pair_totals, dim3(1), dim3(1), 0, st, (const int64_t*)(scal + 3), (const int64_t*)(scal + 4),
+                     (const unsigned long long*)(scal + 5), hits_cap, hit_bytes_cap, totals);
   GF_HIP(hipGetLastError());
   return GF_OK;
 }

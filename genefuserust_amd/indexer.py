@@ -286,6 +286,9 @@ class Indexer:
         _lib.check(L.gf_index_build(arr, lens, n, C.byref(opts), C.byref(h)))
         self._free()
         self._h = h
+        # Fusion::is_reversed() per gene, for the direction rule of the device-resident pair pipeline
+        rev = np.array([f.is_reversed() for f in self.m_fusions] or [0], dtype=np.uint8)
+        _lib.check(L.gf_index_set_gene_reversed(h, rev.ctypes.data, n))
         self.m_fusion_seq = []
         for c in range(n):
             ln = L.gf_index_fusion_seq(h, c, None, 0)

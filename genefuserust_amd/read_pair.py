@@ -103,8 +103,105 @@ def fast_merge_batch(indexer: Indexer, pairs: Sequence[SequenceReadPair]) -> Lis
             for i in range(len(pairs))]
 
 
+class PairScan(NamedTuple):
+    """What gf_scan_pairs_device leaves in HBM: ``hits`` uint8[cap, 64] (gf_pair_hit records),
+    ``bases`` / ``quals`` uint8 (the matched reads, at seq_offset), ``totals`` int64[8]."""
+    hits: "object"
+    bases: "object"
+    quals: "object"
+    totals: "object"
+
+    def download(self) -> Tuple[np.ndarray, bytes, bytes, dict]:
+        """Synchronises.  (records as PAIR_HIT_DTYPE, bases, quals, totals dict)."""
+        t = self.totals.cpu().numpy()
+        tot = {"hits": int(t[0]), "hit_bytes": int(t[1]), "merged_pairs": int(t[2]), "retried_reads": int(t[3]),
+               "overflow": int(t[4])}
+        k, nb = min(tot["hits"], self.hits.shape[0]), min(tot["hit_bytes"], self.bases.numel())
+        rec = self.hits[:k].cpu().numpy().view(_lib.PAIR_HIT_DTYPE).reshape(-1)
+        return rec, self.bases[:nb].cpu().numpy().tobytes(), self.quals[:nb].cpu().numpy().tobytes(), tot
+
+
+def scan_pairs_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_quals, r_off, max_read_len: int,
+                      pair_id_base: int = 0, hits_cap: Optional[int] = None, bytes_cap: Optional[int] = None,
+                      retry_cap: int = 0, stream=None) -> PairScan:
+    """``PairEndScanner::scan_pair_end`` (pescanner.rs:427-518) for a pack of pairs resident in HBM,
+    one asynchronous call: gf_scan_pairs_device.  No host round trip between merge, the mapping
+    passes, the reverse-complement retries and the compaction of the matched reads."""
+    import torch
+    n = l_off.numel() - 1
+    dev = l_bases.device
+    for t in (l_bases, l_quals, r_bases, r_quals):
+        assert t.dtype == torch.uint8 and t.is_cuda
+    assert l_off.dtype == torch.int64 and r_off.dtype == torch.int64 and r_off.numel() == n + 1
+    st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    hits_cap = max(1024, n // 16) if hits_cap is None else hits_cap
+    bytes_cap = hits_cap * 2 * max(int(max_read_len), 1) if bytes_cap is None else bytes_cap
+    hits = torch.empty((max(hits_cap, 1), 64), dtype=torch.uint8, device=dev)
+    hb = torch.empty(max(bytes_cap, 1), dtype=torch.uint8, device=dev)
+    hq = torch.empty(max(bytes_cap, 1), dtype=torch.uint8, device=dev)
+    totals = torch.zeros(8, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().gf_scan_pairs_device(
+        indexer._handle(), l_bases.data_ptr(), l_quals.data_ptr(), l_off.data_ptr(), l_bases.numel(),
+        r_bases.data_ptr(), r_quals.data_ptr(), r_off.data_ptr(), r_bases.numel(), n, int(max_read_len),
+        int(pair_id_base), int(retry_cap), hits.data_ptr(), hits_cap, hb.data_ptr(), hq.data_ptr(), bytes_cap,
+        totals.data_ptr(), st))
+    return PairScan(hits, hb, hq, totals)
+
+
+def finish_pair_hits(mapper: FusionMapper, rec: np.ndarray, bases: bytes, quals: bytes) -> List[Tuple[int, ReadMatch]]:
+    """The host-side tail for the records of a pair scan: FusionMapper::make_match + calc_distance
+    (fusion_mapper.rs:154-251) on each matched read.  Returns (pair_id, ReadMatch) in push order."""
+    from .indexer import GenePos, SeqMatch
+    src_name = ("merged", "r1", "r2")
+    out: List[Tuple[int, ReadMatch]] = []
+    for h in rec:
+        o, ln = int(h["seq_offset"]), int(h["read_len"])
+        seq = bases[o:o + ln]
+        mp = [SeqMatch(int(h["m"][k]["seq_start"]), int(h["m"][k]["seq_end"]),
+                       GenePos(int(h["m"][k]["contig"]), int(h["m"][k]["position"]))) for k in range(2)]
+        m, _ = mapper._tail(seq, mp)
+        if m is None:   # (make_match returns Some for every two-segment mapping in the required direction)
+            continue
+        m.m_reversed = bool(h["flags"] & 2)
+        m.m_quality = quals[o:o + ln]
+        m.m_source = src_name[int(h["source"])]
+        if m.m_source == "merged":
+            m.m_merge_diff = int(h["merge_diff"])
+        out.append((int(h["pair_id"]), m))
+    return out
+
+
 def scan_pair_end(mapper: FusionMapper, pairs: Sequence[SequenceReadPair]) -> List[List[ReadMatch]]:
-    """pescanner.rs:427-518 for a pack of pairs, three GPU steps instead of up to five
+    """pescanner.rs:427-518 for a pack of pairs: upload the pack, ONE device call
+    (``scan_pairs_device``), download the matched reads, finish them on the host.  Returns, per
+    pair, the matches in the order the reference pushes them."""
+    import torch
+    if not pairs:
+        return []
+    ix = mapper.m_indexer
+    dev = torch.device("cuda", ix.info()["device"])
+    lb, lo = pack_reads([p.m_left[0] for p in pairs])
+    lq, _ = pack_reads([p.m_left[1] for p in pairs])
+    rb, ro = pack_reads([p.m_right[0] for p in pairs])
+    rq, _ = pack_reads([p.m_right[1] for p in pairs])
+    t = [torch.from_numpy(a).to(dev) for a in (lb, lq, lo, rb, rq, ro)]
+    max_len = max(int(np.diff(lo).max()), int(np.diff(ro).max()), 1)
+    n = len(pairs)
+    res = scan_pairs_device(ix, *t, max_len, hits_cap=3 * n, bytes_cap=int(lb.size + rb.size) * 2 + 64)
+    rec, hb, hq, tot = res.download()
+    if tot["overflow"] & 1:   # more reverse-complement retries than the default capacity: once more with room for all
+        res = scan_pairs_device(ix, *t, max_len, hits_cap=3 * n, bytes_cap=int(lb.size + rb.size) * 2 + 64, retry_cap=3 * n)
+        rec, hb, hq, tot = res.download()
+    assert not tot["overflow"], tot
+    out: List[List[ReadMatch]] = [[] for _ in pairs]
+    for p, m in finish_pair_hits(mapper, rec, hb, hq):
+        out[p].append(m)
+    return out
+
+
+def scan_pair_end_stepwise(mapper: FusionMapper, pairs: Sequence[SequenceReadPair]) -> List[List[ReadMatch]]:
+    """The same policy with the host between the steps (the first form; kept as a second
+    implementation the device pipeline is tested against): three GPU steps instead of up to five
     ``map_read`` calls per pair: merge all pairs; map the merged read of every pair that
     merged and R1, R2 of every pair that did not (one batch); map the reverse complement of
     every candidate that was mapable but gave no match (one smaller batch).  Returns, per

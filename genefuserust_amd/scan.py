@@ -17,7 +17,7 @@ from .fastq import FastqReader, FastqReaderPair, record_lines
 from .fusion_mapper import FusionMapper, ReadMatch
 from .fusion_result import FusionResult, Settings, cluster_matches, group_and_sort, report_json, report_text
 from .indexer import FastaReader, Fusion, Indexer
-from .read_pair import SequenceReadPair, scan_pair_end
+from .read_pair import finish_pair_hits, scan_pairs_device
 
 
 def scan_pair_end_files(ref_file: str, fusion_csv: str, read1_file: str, read2_file: str, device: int = -1,
@@ -33,28 +33,29 @@ def scan_pair_end_files(ref_file: str, fusion_csv: str, read1_file: str, read2_f
     ix.make_index()
     try:
         (l, ltext), (r, rtext) = FastqReaderPair.from_paths(read1_file, read2_file).read_all_device(ix)
-        lo, ro = l.offsets.cpu().numpy(), r.offsets.cpu().numpy()
-        lb, lq = l.bases.cpu().numpy().tobytes(), l.quals.cpu().numpy().tobytes()
-        rb, rq = r.bases.cpu().numpy().tobytes(), r.quals.cpu().numpy().tobytes()
-        pairs = [SequenceReadPair((lb[lo[i]:lo[i + 1]], lq[lo[i]:lo[i + 1]]), (rb[ro[i]:ro[i + 1]], rq[ro[i]:ro[i + 1]]))
-                 for i in range(l.n_records)]
         mapper = FusionMapper(ix)
-        per_pair = scan_pair_end(mapper, pairs)
+        # the records never leave HBM between the FASTQ cut and the hit list: one device call for the pack
+        n = l.n_records
+        max_len = max(l.max_read_len(), r.max_read_len(), 1)
+        caps = dict(hits_cap=max(1024, n // 8), bytes_cap=max(1024, n // 8) * 2 * max_len)
+        rec, hb, hq, tot = scan_pairs_device(ix, l.bases, l.quals, l.offsets, r.bases, r.quals, r.offsets, max_len,
+                                             **caps).download()
+        if tot["overflow"]:   # unusually many matches or retries: once more with room for everything
+            caps = dict(hits_cap=3 * n, bytes_cap=2 * int(l.bases.numel() + r.bases.numel()) + 64, retry_cap=3 * n)
+            rec, hb, hq, tot = scan_pairs_device(ix, l.bases, l.quals, l.offsets, r.bases, r.quals, r.offsets, max_len,
+                                                 **caps).download()
         found: List[ReadMatch] = []
-        for i, ms in enumerate(per_pair):
-            if not ms:
-                continue
-            name1 = record_lines(l, ltext, i)[0]
-            name2 = record_lines(r, rtext, i)[0]
-            for m in ms:  # a match on R2 (or its reverse complement) carries R2's name; anything else R1's
-                m.m_name = name2 if m.m_source == "r2" else name1
-                if m.m_source == "merged":
-                    m.m_name += b" merged_diff_%d" % m.m_merge_diff
-                found.append(m)
+        for i, m in finish_pair_hits(mapper, rec, hb, hq):
+            # a match on R2 (or its reverse complement) carries R2's name; anything else R1's
+            m.m_name = record_lines(r, rtext, i)[0] if m.m_source == "r2" else record_lines(l, ltext, i)[0]
+            if m.m_source == "merged":
+                m.m_name += b" merged_diff_%d" % m.m_merge_diff
+            found.append(m)
         kept, removed = mapper.filter_matches(found, deletion_threshold)
         if remove_alignables:  # (the reference always does: a whole-genome scan that removes nothing)
             kept, removed["alignables"] = mapper.remove_alignables(kept)
-        counters = {"pairs": l.n_records, "matches_before_filtering": len(found), **removed}
+        counters = {"pairs": l.n_records, "matches_before_filtering": len(found), "merged_pairs": tot["merged_pairs"],
+                    "retried_reads": tot["retried_reads"], **removed}
         if _keep is not None:
             _keep.update(fusions=fusions, fusion_seq=list(ix.m_fusion_seq))
         return FusionMapper.sort_matches(kept), counters

@@ -195,3 +195,87 @@ def ragged_batch(seqs: List[bytes]) -> Tuple[np.ndarray, np.ndarray]:
     np.cumsum(lens, out=offsets[1:])
     bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
     return bases, offsets
+
+
+@dataclass
+class PairBatch:
+    """Read pairs as the FASTQ cut leaves them: R1 = l_*, R2 = r_* (not reverse-complemented),
+    fixed read length, so both files share one offsets array."""
+    l_bases: torch.Tensor
+    l_quals: torch.Tensor
+    r_bases: torch.Tensor
+    r_quals: torch.Tensor
+    offsets: torch.Tensor
+    kinds: torch.Tensor      # 0 background, 1 single gene, 2 junction
+    frag_len: torch.Tensor
+
+    @property
+    def n(self) -> int:
+        return self.offsets.numel() - 1
+
+
+def make_pairs(genes: GeneSet, n: int, read_len: int = 150, mix: str = "PANEL", seed: int = 20240116,
+               device: str = "cpu", chunk: int = 1 << 19, frag_mean: float = 300.0, frag_sd: float = 30.0) -> PairBatch:
+    """Paired reads per SURVEY.md §8(d): a fragment of N(300, 30) bases clipped to [read_len, 500] —
+    background (random), from one gene, or across a junction of two genes (break at least 40 bases from
+    either end) — on either strand; R1 = its first read_len bases, R2 = the reverse complement of its
+    last read_len bases.  0.5 % of the bases of each read are substituted and carry quality '#', the rest
+    'F', so that overlapping mates still merge (fast_merge accepts a mismatch of a high against a low
+    quality, read.rs:313-440)."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    L, FMAX = read_len, 500
+    cat = np.frombuffer(b"".join(genes.seqs), dtype=np.uint8)
+    G = torch.from_numpy(cat.copy()).to(dev)
+    glen = torch.tensor([len(s) for s in genes.seqs], dtype=torch.int64, device=dev)
+    goff = torch.cumsum(glen, 0) - glen
+    usable = (glen >= 2 * FMAX).nonzero().flatten()
+    if usable.numel() == 0:
+        raise ValueError("no gene long enough for fragments of %d bases" % FMAX)
+    acgt = torch.from_numpy(_ACGT.copy()).to(dev)
+    comp = torch.from_numpy(_COMP_LUT.copy()).to(dev)
+    p_bg, p_single, _ = MIXES[mix]
+    ar = torch.arange(FMAX, device=dev, dtype=torch.int64)
+    arL = torch.arange(L, device=dev, dtype=torch.int64)
+    out = {k: torch.empty((n, L), dtype=torch.uint8, device=dev) for k in ("lb", "lq", "rb", "rq")}
+    kinds = torch.empty(n, dtype=torch.uint8, device=dev)
+    flens = torch.empty(n, dtype=torch.int64, device=dev)
+
+    def rnd(shape):
+        return torch.rand(shape, generator=gen, device=dev)
+
+    def rint(hi, shape):
+        return torch.randint(0, hi, shape, generator=gen, device=dev, dtype=torch.int64)
+
+    for c0 in range(0, n, chunk):
+        m = min(chunk, n - c0)
+        u = rnd((m,))
+        kind = torch.where(u < p_bg, 0, torch.where(u < p_bg + p_single, 1, 2)).to(torch.uint8)
+        flen = (frag_mean + frag_sd * torch.randn((m,), generator=gen, device=dev)).round().to(torch.int64).clamp_(L, FMAX)
+        frag = acgt[rint(4, (m, FMAX))]
+        g1 = usable[rint(usable.numel(), (m,))]
+        g2 = usable[rint(usable.numel(), (m,))]
+        o1 = (rnd((m,)) * (glen[g1] - FMAX).to(torch.float64)).to(torch.int64).clamp_(min=0)
+        o2 = (rnd((m,)) * (glen[g2] - FMAX).to(torch.float64)).to(torch.int64).clamp_(min=0)
+        single = G[(goff[g1] + o1)[:, None] + ar[None, :]]
+        brk = 40 + (rnd((m,)) * (flen - 80).to(torch.float64)).to(torch.int64)
+        right = G[((goff[g2] + o2)[:, None] + (ar[None, :] - brk[:, None])).clamp_(0, G.numel() - 1)]
+        junction = torch.where(ar[None, :] < brk[:, None], single, right)
+        frag = torch.where((kind == 1)[:, None], single, frag)
+        frag = torch.where((kind == 2)[:, None], junction, frag)
+        flip = rnd((m,)) < 0.5   # the fragment's other strand
+        rc_frag = comp[torch.gather(frag, 1, (flen[:, None] - 1 - ar[None, :]).clamp_(min=0)).to(torch.int64)]
+        frag = torch.where(flip[:, None], rc_frag, frag)
+        r1 = frag[:, :L]
+        r2 = comp[torch.gather(frag, 1, flen[:, None] - 1 - arL[None, :]).to(torch.int64)]
+        for name, rd in (("l", r1), ("r", r2)):
+            err = rnd((m, L)) < 0.005
+            sub = acgt[rint(4, (m, L))]
+            out[name + "b"][c0:c0 + m] = torch.where(err, sub, rd)
+            out[name + "q"][c0:c0 + m] = torch.where(err, torch.full_like(rd, ord("#")), torch.full_like(rd, ord("F")))
+        kinds[c0:c0 + m] = kind
+        flens[c0:c0 + m] = flen
+    offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
+    return PairBatch(out["lb"].reshape(-1), out["lq"].reshape(-1), out["rb"].reshape(-1), out["rq"].reshape(-1), offsets,
+                     kinds, flens)

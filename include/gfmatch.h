@@ -261,6 +261,46 @@ int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_by
                            int64_t n_newlines, int64_t n_records, void* d_offsets, void* d_bases, void* d_quals,
                            int64_t cap_bytes, void* d_n_bad, void* d_workspace, void* stream);
 
+/* --- the pair policy, device resident --------------------
+ * PairEndScanner::scan_pair_end (pescanner.rs:427-518) for a pack of n pairs whose records are in
+ * HBM (the layout gf_fastq_gather_device writes and gf_fast_merge_*_device take; l_bytes / r_bytes =
+ * bytes in the R1 / R2 base buffers = offsets[n]):
+ *   merged = pair.fast_merge() (:438); a pair that merged is searched as its merged read only
+ *   (:446-471), the others as R1 and then R2 (:473-515); a read that mapped to two places in the
+ *   wrong direction (`mapable` without a match, fusion_mapper.rs:107-123) is searched again as its
+ *   reverse complement (SequenceRead::reverse_complement, read.rs:243-261: qualities reversed).
+ * Output: one gf_pair_hit per read on which FusionMapper::map_read would call make_match — two
+ * segments in the required direction — in the order the reference pushes them (pair, then merged |
+ * R1, R2), with that read's bases and qualities (the reverse complement's when the match is on it)
+ * copied to d_hit_bases / d_hit_quals at seq_offset: what gf_index_fusion_map_read needs to finish
+ * the ReadMatch on the host.  Nothing is synchronised and nothing goes through the host between the
+ * steps (merge-find, slots, merge-write, three mapping passes, classification, reverse
+ * complements, a fourth mapping pass over those, ordered compaction).
+ * flags bit 0: the match is on the reverse complement; bit 1: ReadMatch.m_reversed as the reference
+ * sets it — for R1 / R2 (:489,:511) but NOT for a merged read (:465-468).
+ * d_totals (int64[8], device): [0] hits, [1] bytes of their reads, [2] pairs that merged,
+ * [3] reads searched again reversed, [4] overflow bits — 1: more retries than retry_cap reads (the
+ * retry pass was emptied: run the pack again with retry_cap = 3 n), 2: more hits / bytes than the
+ * output capacities (totals [0], [1] say how many).  retry_cap <= 0: gf_scan_pairs_retry_capacity(n).
+ * gene_reversed flags for the direction rule come from gf_index_set_gene_reversed (all false until set). */
+typedef struct gf_pair_hit {
+  int64_t pair_id;     /* pair_id_base + index of the pair in the pack */
+  int32_t source;      /* 0 = merged read, 1 = R1, 2 = R2 */
+  int32_t flags;
+  int32_t read_len;    /* length of the matched read (bases at seq_offset) */
+  int32_t merge_diff;  /* source 0: the N of the " merged_diff_N" name suffix (read.rs:372) */
+  int64_t seq_offset;  /* into d_hit_bases / d_hit_quals */
+  gf_seqmatch m[2];    /* Indexer::map_read of that read: TOP, SECOND */
+} gf_pair_hit;
+
+int gf_index_set_gene_reversed(gf_index* idx, const uint8_t* gene_reversed, int32_t n_genes);
+int64_t gf_scan_pairs_retry_capacity(int64_t n);
+int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
+                         int64_t l_bytes, const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets,
+                         int64_t r_bytes, int64_t n, int32_t max_read_len, int64_t pair_id_base, int64_t retry_cap,
+                         void* d_hits, int64_t hits_cap, void* d_hit_bases, void* d_hit_quals, int64_t hit_bytes_cap,
+                         void* d_totals, void* stream);
+
 /* --- instrumentation -------------------------------------------------------
  * With profiling on, gf_map_reads_device brackets its mapping kernel with HIP
  * events on the launch stream; gf_last_map_kernel_ms synchronises on them and
