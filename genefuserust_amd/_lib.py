@@ -152,6 +152,20 @@ def lib() -> C.CDLL:
     L.gf_scan_pairs_retry_capacity.restype = i64
     L.gf_scan_pairs_device.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, i32, i64, i64, vp, i64, vp, vp, i64, vp, vp]
     L.gf_scan_pairs_device.restype = C.c_int
+    L.gf_index_trim.argtypes = [vp]
+    L.gf_index_trim.restype = C.c_int
+    L.gf_stream_open.argtypes = [vp, i64, i64, i32, C.POINTER(vp)]
+    L.gf_stream_open.restype = C.c_int
+    L.gf_stream_submit.argtypes = [vp, vp, vp, i64, i64]
+    L.gf_stream_submit.restype = C.c_int
+    L.gf_stream_collect.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.gf_stream_collect.restype = C.c_int
+    L.gf_stream_close.argtypes = [vp]
+    L.gf_stream_close.restype = None
+    L.gf_host_alloc.argtypes = [i64]
+    L.gf_host_alloc.restype = vp
+    L.gf_host_free.argtypes = [vp]
+    L.gf_host_free.restype = None
     L.gf_edit_distance.argtypes = [C.c_char_p, i64, C.c_char_p, i64]
     L.gf_edit_distance.restype = i64
     L.gf_set_profiling.argtypes = [vp, i32]

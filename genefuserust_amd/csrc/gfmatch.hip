@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -113,15 +114,16 @@ struct gf_index {
   std::map<hipStream_t, Workspace> ws_pair;
   std::mutex pair_mu;
   uint8_t* d_gene_rev = nullptr;  // Fusion::is_reversed() per gene (gf_index_set_gene_reversed)
-  // device arena of the host-buffer entry points (gf_map_reads, gf_map_reads_hits), grow-only
-  void* stage_base = nullptr;
-  size_t stage_bytes = 0;
-  std::mutex stage_mu;
+  // lanes of the host-buffer entry points (gf_map_reads, gf_map_read, gf_map_reads_hits): see HostLane
+  std::vector<struct HostLane*> lanes;
+  std::mutex lane_mu;
+  std::condition_variable lane_cv;
   hipEvent_t ev0{}, ev1{};
   hipEvent_t ev_stage[5]{};  // pipeline stage boundaries: seed+verify | filter | buckets | exact kernel
   bool stages_recorded = false;
   std::mutex prof_mu;
 
+  void free_lanes();
   ~gf_index() {
     if (d_slots) (void)hipFree(d_slots);
     if (d_dupes) (void)hipFree(d_dupes);
@@ -135,7 +137,7 @@ struct gf_index {
     for (auto& kv : ws_pair)
       if (kv.second.base) (void)hipFree(kv.second.base);
     if (d_gene_rev) (void)hipFree(d_gene_rev);
-    if (stage_base) (void)hipFree(stage_base);
+    free_lanes();
     if (have_events) {
       (void)hipEventDestroy(ev0);
       (void)hipEventDestroy(ev1);
@@ -649,11 +651,78 @@ int gf_compact_hits_device(const gf_index* idx, const void* d_counts, const void
   return GF_OK;
 }
 
-// Host-buffer staging shared by gf_map_reads / gf_map_reads_hits.
-// Host-buffer entry points: one grow-only device arena per index (bases, offsets, counts,
-// matches, hits, compaction workspace), reused from call to call — for a PCIe-bound path the
-// per-call hipMalloc/hipFree of gigabyte buffers cost as much as the copies.  Calls that go
-// through it are serialised by stage_mu.
+// ---- host-buffer entry points ---------------------------------------------------------------
+// A host-buffer call (gf_map_reads, gf_map_read, gf_map_reads_hits) borrows a LANE of the index: a
+// stream of its own, a grow-only device arena (bases, offsets, counts, matches, hits, compaction
+// workspace) and a small pinned block for what comes back.  Lanes are what makes the boundary
+// usable the way the reference uses Indexer::map_read — from t-1 consumer threads on one `&self`
+// (pescanner.rs:296-311): concurrent callers get different lanes, so their copies and kernels
+// overlap instead of queueing behind one mutex; a caller waits only when all lanes are taken.
+// (For a PCIe-bound path the per-call hipMalloc/hipFree of gigabyte buffers cost as much as the
+// copies: hence the arenas.)
+struct HostLane {
+  hipStream_t st = nullptr;
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  uint8_t* pinned = nullptr;  // host, pinned + device-visible: results of small calls, totals
+  size_t pinned_bytes = 0;
+  bool busy = false;
+};
+
+struct LaneLease {
+  gf_index* ix;
+  HostLane* lane = nullptr;
+  explicit LaneLease(gf_index* i) : ix(i) {}
+  int acquire();
+  ~LaneLease();
+};
+
+static const int GF_MAX_LANES = 8;
+
+void gf_index::free_lanes() {
+  for (HostLane* L : lanes) {
+    if (L->arena) (void)hipFree(L->arena);
+    if (L->pinned) (void)hipHostFree(L->pinned);
+    if (L->st) (void)hipStreamDestroy(L->st);
+    delete L;
+  }
+  lanes.clear();
+}
+
+int LaneLease::acquire() {
+  std::unique_lock<std::mutex> lk(ix->lane_mu);
+  for (;;) {
+    for (HostLane* L : ix->lanes)
+      if (!L->busy) {
+        L->busy = true;
+        lane = L;
+        return GF_OK;
+      }
+    if ((int)ix->lanes.size() < GF_MAX_LANES) {
+      HostLane* L = new HostLane();
+      hipError_t e = hipStreamCreateWithFlags(&L->st, hipStreamNonBlocking);
+      if (e != hipSuccess) {
+        delete L;
+        return fail(GF_ERR_HIP, std::string("hipStreamCreateWithFlags failed: ") + hipGetErrorString(e));
+      }
+      L->busy = true;
+      ix->lanes.push_back(L);
+      lane = L;
+      return GF_OK;
+    }
+    ix->lane_cv.wait(lk);  // every lane is taken by another caller
+  }
+}
+
+LaneLease::~LaneLease() {
+  if (!lane) return;
+  {
+    std::lock_guard<std::mutex> lk(ix->lane_mu);
+    lane->busy = false;
+  }
+  ix->lane_cv.notify_one();
+}
+
 struct HostStage {
   uint8_t* bases = nullptr;     // device pointer such that bases + offsets[r] is read r (host offsets kept as they are)
   int64_t* offsets = nullptr;
@@ -664,8 +733,36 @@ struct HostStage {
   uint8_t* compact_ws = nullptr;
 };
 
-static int stage_and_map(gf_index* mix, const char* bases, const int64_t* offsets, int64_t n, int64_t hits_cap,
-                         HostStage& S) {
+static int lane_reserve(HostLane& L, size_t need) {
+  if (L.arena_bytes >= need) return GF_OK;
+  if (L.arena) {
+    GF_HIP(hipStreamSynchronize(L.st));
+    GF_HIP(hipFree(L.arena));
+    L.arena = nullptr;
+    L.arena_bytes = 0;
+  }
+  GF_HIP(hipMalloc(&L.arena, need));
+  L.arena_bytes = need;
+  return GF_OK;
+}
+
+static int lane_reserve_pinned(HostLane& L, size_t need) {
+  if (L.pinned_bytes >= need) return GF_OK;
+  if (L.pinned) {
+    GF_HIP(hipStreamSynchronize(L.st));
+    GF_HIP(hipHostFree(L.pinned));
+    L.pinned = nullptr;
+    L.pinned_bytes = 0;
+  }
+  need = std::max<size_t>(need, 64 * 1024);
+  GF_HIP(hipHostMalloc((void**)&L.pinned, need, hipHostMallocDefault));
+  L.pinned_bytes = need;
+  return GF_OK;
+}
+
+// validates the batch, sizes the lane's arena, queues the copies in and the mapping on the lane's stream
+static int stage_and_map(gf_index* mix, HostLane& L, const char* bases, const int64_t* offsets, int64_t n,
+                         int64_t hits_cap, HostStage& S) {
   if (n < 0) return fail(GF_ERR_ARG, "negative n");
   if (n > 0 && (!offsets)) return fail(GF_ERR_ARG, "offsets is null");
   int64_t maxlen = 0;
@@ -682,18 +779,9 @@ static int stage_and_map(gf_index* mix, const char* bases, const int64_t* offset
   const size_t sz_counts = al((size_t)n + 1), sz_matches = al(((size_t)n * 2 + 1) * sizeof(gf_seqmatch));
   const size_t sz_hits = al(((size_t)hits_cap + 1) * sizeof(gf_hit)), sz_total = 256;
   const size_t sz_cws = al((size_t)gf_compact_workspace_bytes(n) + 16);
-  const size_t need = sz_bases + sz_off + sz_counts + sz_matches + sz_hits + sz_total + sz_cws;
-  if (mix->stage_bytes < need) {
-    if (mix->stage_base) {
-      GF_HIP(hipDeviceSynchronize());
-      GF_HIP(hipFree(mix->stage_base));
-      mix->stage_base = nullptr;
-      mix->stage_bytes = 0;
-    }
-    GF_HIP(hipMalloc(&mix->stage_base, need));
-    mix->stage_bytes = need;
-  }
-  uint8_t* wp = (uint8_t*)mix->stage_base;
+  int rc = lane_reserve(L, sz_bases + sz_off + sz_counts + sz_matches + sz_hits + sz_total + sz_cws);
+  if (rc != GF_OK) return rc;
+  uint8_t* wp = (uint8_t*)L.arena;
   uint8_t* d_bases = wp; wp += sz_bases;
   S.offsets = (int64_t*)wp; wp += sz_off;
   S.counts = wp; wp += sz_counts;
@@ -705,30 +793,113 @@ static int stage_and_map(gf_index* mix, const char* bases, const int64_t* offset
   const size_t lead = (size_t)((uintptr_t)(bases + b0) & 15u);
   S.bases = d_bases + lead - b0;  // S.bases + offsets[r] = the device copy of read r
   if (n == 0) return GF_OK;
-  if (b1 > b0) GF_HIP(hipMemcpyAsync(d_bases + lead, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, nullptr));
-  GF_HIP(hipMemcpyAsync(S.offsets, offsets, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, nullptr));
+  if (b1 > b0) GF_HIP(hipMemcpyAsync(d_bases + lead, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, L.st));
+  GF_HIP(hipMemcpyAsync(S.offsets, offsets, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, L.st));
   return gf_map_reads_device(mix, S.bases, S.offsets, n, (int32_t)std::max<int64_t>(maxlen, 1), S.counts, S.matches,
-                             nullptr);
+                             (void*)L.st);
+}
+
+// Calls of a few reads — Indexer::map_read as the reference calls it, one read at a time — skip the
+// copies altogether: the reads are written to the lane's pinned block, ONE launch of the exact
+// wave-per-read kernel fetches them over the link and writes its result back to the same block.
+// (The batch route is an H2D copy, five launches and a D2H copy for the same answer.)
+static const int64_t GF_SMALL_CALL_READS = 64;
+
+static int map_small(gf_index* mix, HostLane& L, const char* bases, const int64_t* offsets, int64_t n,
+                     const uint8_t** out_counts, const gf_seqmatch** out_matches) {
+  int64_t maxlen = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t l = offsets[r + 1] - offsets[r];
+    if (l < 0) return fail(GF_ERR_ARG, "offsets must be non-decreasing");
+    maxlen = std::max(maxlen, l);
+  }
+  if (maxlen > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "a read exceeds GF_MAX_READ_LEN");
+  const int64_t b0 = offsets[0], b1 = offsets[n];
+  if (b1 > b0 && !bases) return fail(GF_ERR_ARG, "bases is null");
+  const size_t sz_off = ((size_t)n + 1) * 8, sz_cnt = ((size_t)n + 15) & ~(size_t)15, sz_m = (size_t)n * 32;
+  const size_t sz_b = ((size_t)(b1 - b0) + 64 + 15) & ~(size_t)15;
+  int rc = lane_reserve_pinned(L, sz_off + sz_cnt + sz_m + sz_b + 64);
+  if (rc != GF_OK) return rc;
+  int64_t* h_off = (int64_t*)L.pinned;
+  gf_seqmatch* h_m = (gf_seqmatch*)(L.pinned + sz_off);
+  uint8_t* h_cnt = L.pinned + sz_off + sz_m;
+  uint8_t* h_b = L.pinned + sz_off + sz_m + sz_cnt;
+  for (int64_t r = 0; r <= n; ++r) h_off[r] = offsets[r] - b0;
+  if (b1 > b0) memcpy(h_b, bases + b0, (size_t)(b1 - b0));
+  void* dptr = nullptr;
+  GF_HIP(hipHostGetDevicePointer(&dptr, L.pinned, 0));
+  uint8_t* d = (uint8_t*)dptr;
+  const GfTable T = mix->table;
+  const int grid = (int)n;
+  if (maxlen <= 256)
+    hipLaunchKernelGGL((gf_k_map_reads<256, 1, 0>), dim3(grid), dim3(64), 0, L.st, T, (const uint8_t*)(d + (h_b - L.pinned)),
+                       (const int64_t*)d, n, -1, 1, d + (h_cnt - L.pinned), (gf_seqmatch*)(d + sz_off));
+  else if (maxlen <= 1024)
+    hipLaunchKernelGGL((gf_k_map_reads<1024, 1, 0>), dim3(grid), dim3(64), 0, L.st, T, (const uint8_t*)(d + (h_b - L.pinned)),
+                       (const int64_t*)d, n, -1, 1, d + (h_cnt - L.pinned), (gf_seqmatch*)(d + sz_off));
+  else
+    hipLaunchKernelGGL((gf_k_map_reads<4096, 1, 0>), dim3(grid), dim3(64), 0, L.st, T, (const uint8_t*)(d + (h_b - L.pinned)),
+                       (const int64_t*)d, n, -1, 1, d + (h_cnt - L.pinned), (gf_seqmatch*)(d + sz_off));
+  GF_HIP(hipGetLastError());
+  GF_HIP(hipStreamSynchronize(L.st));
+  *out_counts = h_cnt;
+  *out_matches = h_m;
+  return GF_OK;
 }
 
 int gf_map_reads(const gf_index* idx, const char* bases, const int64_t* offsets, int64_t n,
                  int32_t* out_counts, gf_seqmatch* out_matches) {
   if (n > 0 && (!out_counts || !out_matches)) return fail(GF_ERR_ARG, "null output buffer");
   if (!idx) return fail(GF_ERR_ARG, "null index");
+  if (n < 0) return fail(GF_ERR_ARG, "negative n");
+  if (n > 0 && !offsets) return fail(GF_ERR_ARG, "offsets is null");
+  if (n == 0) return GF_OK;
   DeviceGuard guard(idx->device);
   gf_index* mix = const_cast<gf_index*>(idx);
-  std::lock_guard<std::mutex> lk(mix->stage_mu);
+  LaneLease lease(mix);
+  int rc = lease.acquire();
+  if (rc != GF_OK) return rc;
+  HostLane& L = *lease.lane;
+  if (n <= GF_SMALL_CALL_READS && idx->map_variant == 0) {
+    const uint8_t* c8 = nullptr;
+    const gf_seqmatch* m = nullptr;
+    rc = map_small(mix, L, bases, offsets, n, &c8, &m);
+    if (rc != GF_OK) return rc;
+    for (int64_t r = 0; r < n; ++r) {
+      const int c = c8[r];
+      out_counts[r] = c;
+      for (int k = 0; k < c && k < 2; ++k) out_matches[2 * r + k] = m[2 * r + k];
+    }
+    return GF_OK;
+  }
+  // the dense counts come back whole (a byte per read); of the matches only the reads that have
+  // any (ordered compaction on the device): 48 bytes per hit instead of 32 per read
+  const int64_t cap = std::max<int64_t>(1024, n / 16);
   HostStage S;
-  int rc = stage_and_map(mix, bases, offsets, n, 0, S);
-  if (rc != GF_OK || n == 0) return rc;
+  rc = stage_and_map(mix, L, bases, offsets, n, cap, S);
+  if (rc != GF_OK) return rc;
+  rc = gf_compact_hits_device(idx, S.counts, S.matches, n, 0, S.hits, cap, S.total, S.compact_ws, (void*)L.st);
+  if (rc != GF_OK) return rc;
   std::vector<uint8_t> c8((size_t)n);
-  std::vector<gf_seqmatch> m((size_t)n * 2);
-  GF_HIP(hipMemcpy(c8.data(), S.counts, (size_t)n, hipMemcpyDeviceToHost));
-  GF_HIP(hipMemcpy(m.data(), S.matches, (size_t)n * 2 * sizeof(gf_seqmatch), hipMemcpyDeviceToHost));
-  for (int64_t r = 0; r < n; ++r) {
-    int c = c8[(size_t)r];
-    out_counts[r] = c;
-    for (int k = 0; k < c && k < 2; ++k) out_matches[2 * r + k] = m[(size_t)(2 * r + k)];
+  int64_t total = 0;
+  GF_HIP(hipMemcpyAsync(c8.data(), S.counts, (size_t)n, hipMemcpyDeviceToHost, L.st));
+  GF_HIP(hipMemcpyAsync(&total, S.total, sizeof total, hipMemcpyDeviceToHost, L.st));
+  GF_HIP(hipStreamSynchronize(L.st));
+  for (int64_t r = 0; r < n; ++r) out_counts[r] = c8[(size_t)r];
+  if (total <= cap) {
+    std::vector<gf_hit> h((size_t)total);
+    if (total > 0) {
+      GF_HIP(hipMemcpyAsync(h.data(), S.hits, (size_t)total * sizeof(gf_hit), hipMemcpyDeviceToHost, L.st));
+      GF_HIP(hipStreamSynchronize(L.st));
+    }
+    for (const gf_hit& x : h)
+      for (int k = 0; k < x.n && k < 2; ++k) out_matches[2 * x.read_id + k] = x.m[k];
+  } else {  // a batch of mostly hits: the dense array after all
+    std::vector<gf_seqmatch> m((size_t)n * 2);
+    GF_HIP(hipMemcpyAsync(m.data(), S.matches, (size_t)n * 2 * sizeof(gf_seqmatch), hipMemcpyDeviceToHost, L.st));
+    GF_HIP(hipStreamSynchronize(L.st));
+    for (int64_t r = 0; r < n; ++r)
+      for (int k = 0; k < c8[(size_t)r] && k < 2; ++k) out_matches[2 * r + k] = m[(size_t)(2 * r + k)];
   }
   return GF_OK;
 }
@@ -751,17 +922,24 @@ int gf_map_reads_hits(const gf_index* idx, const char* bases, const int64_t* off
   *out_n = 0;
   DeviceGuard guard(idx->device);
   gf_index* mix = const_cast<gf_index*>(idx);
-  std::lock_guard<std::mutex> lk(mix->stage_mu);
+  LaneLease lease(mix);
+  int rc = lease.acquire();
+  if (rc != GF_OK) return rc;
+  HostLane& L = *lease.lane;
   HostStage S;
-  int rc = stage_and_map(mix, bases, offsets, n, cap, S);
+  rc = stage_and_map(mix, L, bases, offsets, n, cap, S);
   if (rc != GF_OK || n == 0) return rc;
-  rc = gf_compact_hits_device(idx, S.counts, S.matches, n, read_id_base, S.hits, cap, S.total, S.compact_ws, nullptr);
+  rc = gf_compact_hits_device(idx, S.counts, S.matches, n, read_id_base, S.hits, cap, S.total, S.compact_ws, (void*)L.st);
   if (rc != GF_OK) return rc;
   int64_t total = 0;
-  GF_HIP(hipMemcpy(&total, S.total, sizeof total, hipMemcpyDeviceToHost));  // also waits for the launches
+  GF_HIP(hipMemcpyAsync(&total, S.total, sizeof total, hipMemcpyDeviceToHost, L.st));
+  GF_HIP(hipStreamSynchronize(L.st));  // (the launches are done)
   *out_n = total;
   int64_t ncopy = std::min(total, cap);
-  if (ncopy > 0) GF_HIP(hipMemcpy(out_hits, S.hits, (size_t)ncopy * sizeof(gf_hit), hipMemcpyDeviceToHost));
+  if (ncopy > 0) {
+    GF_HIP(hipMemcpyAsync(out_hits, S.hits, (size_t)ncopy * sizeof(gf_hit), hipMemcpyDeviceToHost, L.st));
+    GF_HIP(hipStreamSynchronize(L.st));
+  }
   return GF_OK;
 }
 
@@ -1252,6 +1430,187 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   hipLaunchKernelGGL(gf_k_pair_totals, dim3(1), dim3(1), 0, st, (const int64_t*)(scal + 3), (const int64_t*)(scal + 4),
                      (const unsigned long long*)(scal + 5), hits_cap, hit_bytes_cap, totals);
   GF_HIP(hipGetLastError());
+  return GF_OK;
+}
+
+// ---- streaming host entry: packs submitted ahead of the ones being mapped ---------------------
+// The consumer loop of the reference takes packs of reads off a queue while the producer keeps
+// reading the FASTQ (pescanner.rs:255-311).  Here a pack is SUBMITTED (copy in, mapping, compaction,
+// hit records out: all queued on the slot's own stream) and COLLECTED later; with `depth` slots the
+// copy of pack k+1 crosses the link while the kernels of pack k run and the hits of pack k-1 go back.
+struct gf_stream {
+  gf_index* ix = nullptr;
+  int depth = 0;
+  int64_t max_reads = 0, max_bytes = 0, pin_cap = 0;
+  struct Slot {
+    hipStream_t st = nullptr;
+    hipEvent_t done{};
+    uint8_t* arena = nullptr;  // device: bases | offsets | counts | matches | hits | total | compaction workspace
+    uint8_t* d_bases = nullptr; int64_t* d_off = nullptr; uint8_t* d_counts = nullptr; gf_seqmatch* d_matches = nullptr;
+    gf_hit* d_hits = nullptr; int64_t* d_total = nullptr; uint8_t* d_cws = nullptr;
+    gf_hit* h_hits = nullptr;  // pinned: the first pin_cap records of the pack
+    int64_t* h_total = nullptr;
+    bool inflight = false;
+    int64_t n = 0;
+  };
+  std::vector<Slot> slots;
+  int head = 0, tail = 0, live = 0;
+};
+
+void* gf_host_alloc(int64_t bytes) {
+  if (bytes <= 0) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+    g_err = "hipHostMalloc failed";
+    return nullptr;
+  }
+  return p;
+}
+
+void gf_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+void gf_stream_close(gf_stream* s) {
+  if (!s) return;
+  DeviceGuard guard(s->ix->device);
+  for (auto& sl : s->slots) {
+    if (sl.st) (void)hipStreamSynchronize(sl.st);
+    if (sl.arena) (void)hipFree(sl.arena);
+    if (sl.h_hits) (void)hipHostFree(sl.h_hits);
+    if (sl.h_total) (void)hipHostFree(sl.h_total);
+    if (sl.st) {
+      (void)hipEventDestroy(sl.done);
+      // the mapping workspace cached for this stream goes with it
+      std::lock_guard<std::mutex> lk(s->ix->ws_mu);
+      auto it = s->ix->ws.find(sl.st);
+      if (it != s->ix->ws.end()) {
+        if (it->second.base) (void)hipFree(it->second.base);
+        s->ix->ws.erase(it);
+      }
+      (void)hipStreamDestroy(sl.st);
+    }
+  }
+  delete s;
+}
+
+int gf_stream_open(const gf_index* idx, int64_t max_reads, int64_t max_bytes, int32_t depth, gf_stream** out) {
+  if (!out) return fail(GF_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (!idx || max_reads <= 0 || max_bytes < 0 || depth < 1 || depth > 16) return fail(GF_ERR_ARG, "bad argument");
+  DeviceGuard guard(idx->device);
+  std::unique_ptr<gf_stream, void (*)(gf_stream*)> s(new gf_stream(), gf_stream_close);
+  s->ix = const_cast<gf_index*>(idx);
+  s->depth = depth;
+  s->max_reads = max_reads;
+  s->max_bytes = max_bytes;
+  s->pin_cap = std::max<int64_t>(4096, max_reads / 16);
+  s->slots.resize((size_t)depth);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t sz_b = al((size_t)max_bytes + 64), sz_o = al(((size_t)max_reads + 1) * 8), sz_c = al((size_t)max_reads + 1);
+  const size_t sz_m = al(((size_t)max_reads * 2 + 1) * sizeof(gf_seqmatch)), sz_h = al(((size_t)max_reads + 1) * sizeof(gf_hit));
+  const size_t sz_w = al((size_t)gf_compact_workspace_bytes(max_reads) + 16);
+  for (auto& sl : s->slots) {
+    GF_HIP(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+    GF_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    GF_HIP(hipMalloc((void**)&sl.arena, sz_b + sz_o + sz_c + sz_m + sz_h + 256 + sz_w));
+    uint8_t* wp = sl.arena;
+    sl.d_bases = wp; wp += sz_b;
+    sl.d_off = (int64_t*)wp; wp += sz_o;
+    sl.d_counts = wp; wp += sz_c;
+    sl.d_matches = (gf_seqmatch*)wp; wp += sz_m;
+    sl.d_hits = (gf_hit*)wp; wp += sz_h;
+    sl.d_total = (int64_t*)wp; wp += 256;
+    sl.d_cws = wp;
+    GF_HIP(hipHostMalloc((void**)&sl.h_hits, (size_t)s->pin_cap * sizeof(gf_hit), hipHostMallocDefault));
+    GF_HIP(hipHostMalloc((void**)&sl.h_total, 64, hipHostMallocDefault));
+  }
+  *out = s.release();
+  return GF_OK;
+}
+
+int gf_stream_submit(gf_stream* s, const char* bases, const int64_t* offsets, int64_t n, int64_t read_id_base) {
+  if (!s || n < 0 || (n > 0 && !offsets)) return fail(GF_ERR_ARG, "bad argument");
+  if (n > s->max_reads) return fail(GF_ERR_CAPACITY, "pack has more reads than the stream was opened for");
+  if (s->live == s->depth) return fail(GF_ERR_CAPACITY, "every slot is in flight: collect a pack first");
+  int64_t maxlen = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t l = offsets[r + 1] - offsets[r];
+    if (l < 0) return fail(GF_ERR_ARG, "offsets must be non-decreasing");
+    maxlen = std::max(maxlen, l);
+  }
+  if (maxlen > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "a read exceeds GF_MAX_READ_LEN");
+  const int64_t b0 = n > 0 ? offsets[0] : 0, b1 = n > 0 ? offsets[n] : 0;
+  if (b1 - b0 > s->max_bytes) return fail(GF_ERR_CAPACITY, "pack has more bytes than the stream was opened for");
+  if (b1 > b0 && !bases) return fail(GF_ERR_ARG, "bases is null");
+  DeviceGuard guard(s->ix->device);
+  gf_stream::Slot& sl = s->slots[(size_t)s->head];
+  sl.n = n;
+  if (n > 0) {
+    const size_t lead = (size_t)((uintptr_t)(bases + b0) & 15u);  // keep the span's 16-byte phase
+    if (b1 > b0) GF_HIP(hipMemcpyAsync(sl.d_bases + lead, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, sl.st));
+    GF_HIP(hipMemcpyAsync(sl.d_off, offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, sl.st));
+    int rc = gf_map_reads_device(s->ix, sl.d_bases + lead - b0, sl.d_off, n, (int32_t)std::max<int64_t>(maxlen, 1),
+                                 sl.d_counts, sl.d_matches, (void*)sl.st);
+    if (rc != GF_OK) return rc;
+    rc = gf_compact_hits_device(s->ix, sl.d_counts, sl.d_matches, n, read_id_base, sl.d_hits, n, sl.d_total, sl.d_cws,
+                                (void*)sl.st);
+    if (rc != GF_OK) return rc;
+    GF_HIP(hipMemcpyAsync(sl.h_total, sl.d_total, 8, hipMemcpyDeviceToHost, sl.st));
+    GF_HIP(hipMemcpyAsync(sl.h_hits, sl.d_hits, (size_t)std::min(n, s->pin_cap) * sizeof(gf_hit), hipMemcpyDeviceToHost,
+                          sl.st));
+  } else {
+    *sl.h_total = 0;
+  }
+  GF_HIP(hipEventRecord(sl.done, sl.st));
+  sl.inflight = true;
+  s->head = (s->head + 1) % s->depth;
+  s->live += 1;
+  return GF_OK;
+}
+
+int gf_stream_collect(gf_stream* s, gf_hit* out_hits, int64_t cap, int64_t* out_n) {
+  if (!s || !out_n || cap < 0 || (cap > 0 && !out_hits)) return fail(GF_ERR_ARG, "bad argument");
+  *out_n = 0;
+  if (s->live == 0) return fail(GF_ERR_ARG, "no pack in flight");
+  DeviceGuard guard(s->ix->device);
+  gf_stream::Slot& sl = s->slots[(size_t)s->tail];
+  GF_HIP(hipEventSynchronize(sl.done));
+  const int64_t total = sl.n > 0 ? *sl.h_total : 0;
+  *out_n = total;
+  const int64_t want = std::min(total, cap);
+  const int64_t from_pin = std::min(want, std::min(sl.n, s->pin_cap));
+  if (from_pin > 0) memcpy(out_hits, sl.h_hits, (size_t)from_pin * sizeof(gf_hit));
+  if (want > from_pin)  // more hits than the pinned block holds: the rest straight from the device list
+    GF_HIP(hipMemcpy(out_hits + from_pin, sl.d_hits + from_pin, (size_t)(want - from_pin) * sizeof(gf_hit),
+                     hipMemcpyDeviceToHost));
+  sl.inflight = false;
+  s->tail = (s->tail + 1) % s->depth;
+  s->live -= 1;
+  return GF_OK;
+}
+
+int gf_index_trim(gf_index* idx) {
+  if (!idx) return fail(GF_ERR_ARG, "null index");
+  DeviceGuard guard(idx->device);
+  {
+    std::lock_guard<std::mutex> lk(idx->lane_mu);
+    for (HostLane* L : idx->lanes) {
+      if (L->busy) continue;  // in use by another thread: left alone
+      if (L->arena) { GF_HIP(hipFree(L->arena)); L->arena = nullptr; L->arena_bytes = 0; }
+      if (L->pinned) { GF_HIP(hipHostFree(L->pinned)); L->pinned = nullptr; L->pinned_bytes = 0; }
+    }
+  }
+  std::lock_guard<std::mutex> l1(idx->pair_mu);
+  std::lock_guard<std::mutex> l2(idx->ws_mu);
+  for (auto* m : {&idx->ws, &idx->ws_pair})
+    for (auto& kv : *m)
+      if (kv.second.base) {
+        GF_HIP(hipStreamSynchronize(kv.first));  // calls queued on that stream may still use it
+        GF_HIP(hipFree(kv.second.base));
+        kv.second.base = nullptr;
+        kv.second.bytes = 0;
+      }
   return GF_OK;
 }
 

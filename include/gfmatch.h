@@ -11,8 +11,18 @@
  * functions return GF_OK (0) or a negative GF_ERR_* code and gf_last_error()
  * holds a message for the calling thread.  There is no CPU fallback: every
  * compute entry point fails with GF_ERR_NO_DEVICE when no HIP device is usable.
- * Concurrent gf_map_* calls on one index are allowed (the index is read-only
- * after gf_index_build, like `&self` in Indexer::map_read).
+ * Concurrent gf_map_* / gf_scan_* / gf_stream_* calls on one index are allowed (the index is
+ * read-only after gf_index_build, like `&self` in Indexer::map_read, which the reference calls
+ * from t-1 consumer threads, pescanner.rs:296-311): host-buffer calls run on up to 8 internal
+ * lanes (stream + arena each) so that callers overlap; device-buffer calls on different streams
+ * are independent, on one stream they run in call order.  Profiling (gf_set_profiling) and
+ * gf_set_map_variant are single-threaded switches for experiments.
+ *
+ * Device buffers: the kernels load whole aligned 16-byte chunks around a batch's span of bases —
+ * up to 15 bytes before d_bases + offsets[0] and up to 15 (FASTQ/merge: 63) past the last base are
+ * READ (never written, never interpreted).  Inside any whole allocation that is always
+ * addressable; a sub-range of a larger buffer is fine too; only a span ending exactly at the end
+ * of a mapping that is not 16-byte padded would not be.
  */
 #ifndef GFMATCH_H
 #define GFMATCH_H
@@ -94,6 +104,13 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
                    const gf_options* opts, gf_index** out_index);
 void gf_index_free(gf_index* idx);
 int gf_index_info_get(const gf_index* idx, gf_index_info* out);
+
+/* Long-lived hosts: the library keeps grow-only device memory between calls — a workspace per
+ * (index, stream) used by gf_map_reads_device / gf_scan_pairs_device (64-112 bytes per read of the
+ * largest span mapped on that stream, at most 2^30 reads per span) and the arenas of the
+ * host-buffer entry points.  gf_index_trim waits for the work queued on those streams and frees
+ * them all (they grow again on demand); gf_index_free frees everything. */
+int gf_index_trim(gf_index* idx);
 
 /* Indexer.m_fusion_seq[c] (indexer.rs:77, :170; read by fusion_mapper.rs:230,
  * :439-452): the upper-cased gene slice, kept on the host.  Returns its length
@@ -300,6 +317,28 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
                          int64_t r_bytes, int64_t n, int32_t max_read_len, int64_t pair_id_base, int64_t retry_cap,
                          void* d_hits, int64_t hits_cap, void* d_hit_bases, void* d_hit_quals, int64_t hit_bytes_cap,
                          void* d_totals, void* stream);
+
+/* --- streaming host entry ----------------------------------------------------------------------
+ * For a host that produces packs of reads while earlier packs are being mapped (the reference's
+ * producer / consumer loop, pescanner.rs:255-311, with the queue on the device side of the link):
+ * gf_stream_submit queues copy-in, mapping, ordered compaction and the copy of the hit records back
+ * on one of `depth` slots (each with its own HIP stream, device arena and pinned result block) and
+ * returns; gf_stream_collect waits for the OLDEST submitted pack and hands out its hits (ascending
+ * read id = read_id_base + index in the pack; *out_n = their number, of which min(cap, *out_n) are
+ * written).  With depth >= 2 the copy of pack k+1 overlaps the kernels of pack k.
+ * `bases` / `offsets` as for gf_map_reads.  When they live in pinned memory (gf_host_alloc) the copy
+ * is asynchronous and the buffers must stay untouched until that pack is collected; from pageable
+ * memory the runtime stages the copy before gf_stream_submit returns.
+ * A gf_stream belongs to one thread at a time; several streams may share an index.
+ * Errors: GF_ERR_CAPACITY when a pack exceeds max_reads / max_bytes or every slot is in flight. */
+typedef struct gf_stream gf_stream;
+int gf_stream_open(const gf_index* idx, int64_t max_reads, int64_t max_bytes, int32_t depth, gf_stream** out);
+int gf_stream_submit(gf_stream* s, const char* bases, const int64_t* offsets, int64_t n, int64_t read_id_base);
+int gf_stream_collect(gf_stream* s, gf_hit* out_hits, int64_t cap, int64_t* out_n);
+void gf_stream_close(gf_stream* s);
+/* pinned host memory for the buffers handed to gf_stream_submit / gf_map_reads* (hipHostMalloc) */
+void* gf_host_alloc(int64_t bytes);
+void gf_host_free(void* p);
 
 /* --- instrumentation -------------------------------------------------------
  * With profiling on, gf_map_reads_device brackets its mapping kernel with HIP

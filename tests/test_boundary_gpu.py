@@ -1,0 +1,71 @@
+"""The boundary under load (needs a GPU): concurrent callers, the small-call route, the streaming
+entry, gf_index_trim.  C++ threads call the C ABI directly (tests/cpp/test_threads.cpp); the Python
+side checks the streaming entry against the one-shot host call on pinned and pageable buffers."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_threads_on_one_index(gpu_device, tmp_path):
+    """T = 8 threads on one index through gf_map_reads / gf_map_reads_hits / gf_map_read / gf_stream_*:
+    every result equals the serial one (pescanner.rs:296-311 calls map_read from t-1 threads)."""
+    exe = str(tmp_path / "test_threads")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "test_threads.cpp"), "-o", exe,
+                    "-L" + os.path.join(ROOT, "genefuserust_amd"), "-lgfmatch",
+                    "-Wl,-rpath," + os.path.join(ROOT, "genefuserust_amd")], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(out.stdout)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "test_threads.log"), "w") as f:
+        f.write(out.stdout)
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_stream_equals_one_shot(gpu_device, pinned):
+    from genefuserust_amd import Indexer, synth
+    from genefuserust_amd.stream import MapStream, pinned_empty
+    genes = synth.make_geneset("IDX-T", scale=0.1)
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    synth.MIXES["TEST"] = (0.2, 0.5, 0.3)
+    n, L = 200_003, 150
+    rb = synth.make_reads(genes, n, read_len=L, mix="TEST", seed=12)
+    bases, offsets = rb.bases.numpy(), rb.offsets.numpy()
+    want = ix.map_reads_hits(bases, offsets, read_id_base=5)
+    assert want.shape[0] > 20_000
+    if pinned:
+        hb, ho = pinned_empty(bases.size, np.uint8), pinned_empty(offsets.size, np.int64)
+        hb[:], ho[:] = bases, offsets
+    else:
+        hb, ho = bases, offsets
+    pack = 30_000
+    got = []
+    with MapStream(ix, max_reads=pack, max_bytes=pack * L, depth=3) as ms:
+        inflight = 0
+        for p0 in range(0, n, pack):
+            p1 = min(n, p0 + pack)
+            if inflight == ms.depth:
+                got.append(ms.collect())
+                inflight -= 1
+            ms.submit(hb, ho[p0:p1 + 1], read_id_base=5 + p0)
+            inflight += 1
+        while inflight:
+            got.append(ms.collect())
+            inflight -= 1
+        # an empty pack, and a pack over the stream's capacity
+        ms.submit(hb, ho[:1])
+        assert ms.collect().shape[0] == 0
+        from genefuserust_amd import _lib
+        with pytest.raises(_lib.GfError) as e:
+            ms.submit(hb, ho[: pack + 2])
+        assert e.value.code == _lib.GF_ERR_CAPACITY
+    got = np.concatenate(got)
+    assert got.tobytes() == want.tobytes()
+    ix.close()

@@ -267,7 +267,8 @@ def test_config4_multi_csv_rebuild_loop(gpu_device, oracle):
     sets = [synth.make_geneset("IDX-C" if k % 2 == 0 else "IDX-D", scale=0.02 if k % 2 == 0 else 0.05, seed=1000 + 37 * k)
             for k in range(n_csv)]
     half = 150_000
-    parts = [synth.make_reads(sets[k], half, read_len=L, mix="PANEL", seed=9 + k, device="cuda") for k in (0, 1, 5)]
+    synth.MIXES["TEST"] = (0.2, 0.5, 0.3)   # junction-heavy: every CSV that owns reads has thousands of hits
+    parts = [synth.make_reads(sets[k], half, read_len=L, mix="TEST", seed=9 + k, device="cuda") for k in (0, 1, 5)]
     bases = torch.cat([p.bases for p in parts])
     n = bases.numel() // L
     offsets = torch.arange(n + 1, device="cuda", dtype=torch.int64) * L
