@@ -385,6 +385,108 @@ __device__ __forceinline__ int gf_first_pass_seed_verify(const GfTable& T, GfMap
   return nvotes;
 }
 
+// segment_mask (indexer.rs:616-679) over the class mask in S.u.p2.mask[0..L): longest run per
+// target (3 = TOP with gp1, then 2 = SECOND with gp2), first start wins ties; writes the read's
+// result.  S.u.p2.wcls is scratch.
+// The reference tries every start s <= L-2 with mask[s] == target and scans forward,
+// jumping gaps of up to 10 lower-class positions and stopping at a higher class.  Two
+// facts make that parallel: (1) from any target position the scan continues the same
+// way wherever it started, so a start that an earlier start's scan reaches can only give
+// a shorter run with the same end — only "heads" (targets no earlier target reaches)
+// matter; (2) the targets between two consecutive heads are exactly the first head's
+// run, so its end is the last target before the next head.  Heads and targets are two
+// bit masks (ballots, 64 positions per step); the few heads are then walked once.
+template <int LCAP>
+__device__ __forceinline__ void gf_segment_mask_wave(GfMapSmem<LCAP>& S, int L, int lane, int64_t gp1, int64_t gp2,
+                                                     int64_t r, uint8_t* __restrict__ counts,
+                                                     gf_seqmatch* __restrict__ matches) {
+  constexpr int NCH = (LCAP + 63) / 64;
+  uint32_t* segT = (uint32_t*)S.u.p2.wcls;        // wcls is dead: reuse it for the masks (32-bit halves)
+  uint32_t* segH = segT + 2 * NCH;
+  static_assert(4 * NCH * 4 <= LCAP, "masks fit in wcls");
+  auto ld64 = [](const uint32_t* a, int c) { return (uint64_t)a[2 * c] | ((uint64_t)a[2 * c + 1] << 32); };
+  const int nch = (L + 63) >> 6;
+  int nout = 0;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int target = t == 0 ? 3 : 2;
+    gf_wave_lds_sync();
+    for (int c = 0; c < nch; ++c) {
+      const int p = 64 * c + lane;
+      const int m = p < L ? (int)S.u.p2.mask[p] : 255;
+      const bool is_t = m == target;
+      bool head = is_t;  // head of a chain: a target no earlier target's scan reaches
+      if (head) {  // reached by an earlier target within the allowed gap, nothing higher in between?
+        for (int k = 1; k <= GF_ALLOWED_GAP && p - k >= 0; ++k) {
+          const int q = (int)S.u.p2.mask[p - k];
+          if (q > target) break;
+          if (q == target) {
+            head = false;
+            break;
+          }
+        }
+      }
+      const uint64_t bt = __ballot(is_t), bh = __ballot(head);
+      if (lane == 0) {
+        segT[2 * c] = (uint32_t)bt; segT[2 * c + 1] = (uint32_t)(bt >> 32);
+        segH[2 * c] = (uint32_t)bh; segH[2 * c + 1] = (uint32_t)(bh >> 32);
+      }
+    }
+    gf_wave_lds_sync();
+    int best_len = -1, best_s = 0;
+    for (int c = 0; c < nch; ++c) {
+      uint64_t h = ld64(segH, c);
+      while (h) {
+        const int b = __builtin_ctzll(h);
+        h &= h - 1;
+        const int s = 64 * c + b;
+        // the next head after s (L if there is none)
+        int nh = L;
+        if (h) {
+          nh = 64 * c + __builtin_ctzll(h);
+        } else {
+          for (int c2 = c + 1; c2 < nch; ++c2) {
+            const uint64_t h2 = ld64(segH, c2);
+            if (h2) {
+              nh = 64 * c2 + __builtin_ctzll(h2);
+              break;
+            }
+          }
+        }
+        // the last target before it: s itself is one
+        int e = s;
+        for (int cw = (nh - 1) >> 6; cw >= c; --cw) {
+          uint64_t tt = ld64(segT, cw);
+          const int hi = nh - 64 * cw;  // keep bits < hi
+          if (hi < 64) tt &= (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
+          if (tt) {
+            e = 64 * cw + 63 - __builtin_clzll(tt);
+            break;
+          }
+        }
+        if (s <= L - 2 && e - s > best_len) {  // (the last position is no start, :631)
+          best_len = e - s;
+          best_s = s;
+        }
+      }
+    }
+    if (best_len > GF_THRESHOLD_LEN) {
+      if (lane == 0) {
+        const int64_t gp = t == 0 ? gp1 : gp2;
+        gf_seqmatch out;
+        out.seq_start = best_s;
+        out.seq_end = best_s + best_len;
+        out.position = (int32_t)(uint32_t)(gp & 0xFFFFFFFFll);  // i64_to_gp, :709-714
+        out.contig = (int16_t)(gp >> 32);
+        out.pad = 0;
+        matches[2 * r + nout] = out;
+      }
+      nout += 1;
+    }
+  }
+  if (lane == 0) counts[r] = (uint8_t)nout;
+}
+
 // ---- 3..5: peel, gate, second pass, segment_mask, output ----
 template <int LCAP>
 __device__ __forceinline__ void gf_finish_read(const GfTable& T, GfMapSmem<LCAP>& S, int L, uint32_t sh,
@@ -496,100 +598,7 @@ __device__ __forceinline__ void gf_finish_read(const GfTable& T, GfMapSmem<LCAP>
   }
   gf_wave_lds_sync();
 
-  // segment_mask: longest run per target, first start wins ties (indexer.rs:616-679).
-  // The reference tries every start s <= L-2 with mask[s] == target and scans forward,
-  // jumping gaps of up to 10 lower-class positions and stopping at a higher class.  Two
-  // facts make that parallel: (1) from any target position the scan continues the same
-  // way wherever it started, so a start that an earlier start's scan reaches can only give
-  // a shorter run with the same end — only "heads" (targets no earlier target reaches)
-  // matter; (2) the targets between two consecutive heads are exactly the first head's
-  // run, so its end is the last target before the next head.  Heads and targets are two
-  // bit masks (ballots, 64 positions per step); the few heads are then walked once.
-  constexpr int NCH = (LCAP + 63) / 64;
-  uint32_t* segT = (uint32_t*)S.u.p2.wcls;        // wcls is dead: reuse it for the masks (32-bit halves)
-  uint32_t* segH = segT + 2 * NCH;
-  static_assert(4 * NCH * 4 <= LCAP, "masks fit in wcls");
-  auto ld64 = [](const uint32_t* a, int c) { return (uint64_t)a[2 * c] | ((uint64_t)a[2 * c + 1] << 32); };
-  const int nch = (L + 63) >> 6;
-  int nout = 0;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int target = t == 0 ? 3 : 2;
-    gf_wave_lds_sync();
-    for (int c = 0; c < nch; ++c) {
-      const int p = 64 * c + lane;
-      const int m = p < L ? (int)S.u.p2.mask[p] : 255;
-      const bool is_t = m == target;
-      bool head = is_t;  // head of a chain: a target no earlier target's scan reaches
-      if (head) {  // reached by an earlier target within the allowed gap, nothing higher in between?
-        for (int k = 1; k <= GF_ALLOWED_GAP && p - k >= 0; ++k) {
-          const int q = (int)S.u.p2.mask[p - k];
-          if (q > target) break;
-          if (q == target) {
-            head = false;
-            break;
-          }
-        }
-      }
-      const uint64_t bt = __ballot(is_t), bh = __ballot(head);
-      if (lane == 0) {
-        segT[2 * c] = (uint32_t)bt; segT[2 * c + 1] = (uint32_t)(bt >> 32);
-        segH[2 * c] = (uint32_t)bh; segH[2 * c + 1] = (uint32_t)(bh >> 32);
-      }
-    }
-    gf_wave_lds_sync();
-    int best_len = -1, best_s = 0;
-    for (int c = 0; c < nch; ++c) {
-      uint64_t h = ld64(segH, c);
-      while (h) {
-        const int b = __builtin_ctzll(h);
-        h &= h - 1;
-        const int s = 64 * c + b;
-        // the next head after s (L if there is none)
-        int nh = L;
-        if (h) {
-          nh = 64 * c + __builtin_ctzll(h);
-        } else {
-          for (int c2 = c + 1; c2 < nch; ++c2) {
-            const uint64_t h2 = ld64(segH, c2);
-            if (h2) {
-              nh = 64 * c2 + __builtin_ctzll(h2);
-              break;
-            }
-          }
-        }
-        // the last target before it: s itself is one
-        int e = s;
-        for (int cw = (nh - 1) >> 6; cw >= c; --cw) {
-          uint64_t tt = ld64(segT, cw);
-          const int hi = nh - 64 * cw;  // keep bits < hi
-          if (hi < 64) tt &= (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
-          if (tt) {
-            e = 64 * cw + 63 - __builtin_clzll(tt);
-            break;
-          }
-        }
-        if (s <= L - 2 && e - s > best_len) {  // (the last position is no start, :631)
-          best_len = e - s;
-          best_s = s;
-        }
-      }
-    }
-    if (best_len > GF_THRESHOLD_LEN) {
-      if (lane == 0) {
-        const int64_t gp = t == 0 ? gp1 : gp2;
-        gf_seqmatch out;
-        out.seq_start = best_s;
-        out.seq_end = best_s + best_len;
-        out.position = (int32_t)(uint32_t)(gp & 0xFFFFFFFFll);  // i64_to_gp, :709-714
-        out.contig = (int16_t)(gp >> 32);
-        out.pad = 0;
-        matches[2 * r + nout] = out;
-      }
-      nout += 1;
-    }
-  }
-  if (lane == 0) counts[r] = (uint8_t)nout;
+  gf_segment_mask_wave<LCAP>(S, L, lane, gp1, gp2, r, counts, matches);
 }
 
 // PRODUCER: 0 = probe all windows, 1 = seed + verify (LCAP <= 256 only)
@@ -713,6 +722,30 @@ __global__ __launch_bounds__(WAVES * 64, 8) void gf_k_map_reads_short(GfTable T,
     }
     cur_off = nxt_off; cur_end = nxt_end; cur_x0 = nxt_x0; cur_x1 = nxt_x1;
     nxt_off = nn_off; nxt_end = nn_end;
+  }
+}
+
+// Test/diagnostic: the device form of segment_mask alone, on class masks given by the caller (one
+// wavefront per mask of lmin < length <= LCAP), so that it can be held against the reference's
+// sequential scan on arbitrary masks and not only on the masks whole reads happen to produce.
+template <int LCAP>
+__global__ __launch_bounds__(64) void gf_k_segment_mask_test(const uint8_t* __restrict__ masks,
+                                                             const int64_t* __restrict__ offsets, int64_t n, int lmin,
+                                                             const int64_t* __restrict__ gp1,
+                                                             const int64_t* __restrict__ gp2,
+                                                             uint8_t* __restrict__ counts,
+                                                             gf_seqmatch* __restrict__ matches) {
+  __shared__ GfMapSmem<LCAP> S;
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const int64_t off0 = offsets[r];
+    const int64_t len64 = offsets[r + 1] - off0;
+    if (len64 <= lmin || len64 > LCAP) continue;
+    const int L = (int)len64;
+    gf_wave_lds_sync();
+    for (int j = lane; j < L; j += 64) S.u.p2.mask[j] = masks[off0 + j];
+    gf_wave_lds_sync();
+    gf_segment_mask_wave<LCAP>(S, L, lane, gp1[r], gp2[r], r, counts, matches);
   }
 }
 

@@ -102,17 +102,6 @@ struct gf_index {
   bool profiling = false;
   bool have_events = false;
   bool recorded = false;
-  // per-stream workspace of the flat pipeline (grow-only).  Calls on one stream run in
-  // order, so the next call may reuse the buffers; launch sequences are serialised by
-  // ws_mu so that two host threads sharing a stream cannot interleave their kernels.
-  // (Stream-ordered hipMallocAsync/hipFreeAsync was tried first: on the legacy default
-  // stream a free issued right after the launches raced with the kernels.)
-  struct Workspace { void* base = nullptr; size_t bytes = 0; };
-  std::map<hipStream_t, Workspace> ws;
-  std::mutex ws_mu;
-  // the pair pipeline's own per-stream workspace (gf_scan_pairs_device), same rules
-  std::map<hipStream_t, Workspace> ws_pair;
-  std::mutex pair_mu;
   uint8_t* d_gene_rev = nullptr;  // Fusion::is_reversed() per gene (gf_index_set_gene_reversed)
   // lanes of the host-buffer entry points (gf_map_reads, gf_map_read, gf_map_reads_hits): see HostLane
   std::vector<struct HostLane*> lanes;
@@ -132,10 +121,6 @@ struct gf_index {
     if (d_gene_len) (void)hipFree(d_gene_len);
     if (d_gdu) (void)hipFree(d_gdu);
     if (d_bloom) (void)hipFree(d_bloom);
-    for (auto& kv : ws)
-      if (kv.second.base) (void)hipFree(kv.second.base);
-    for (auto& kv : ws_pair)
-      if (kv.second.base) (void)hipFree(kv.second.base);
     if (d_gene_rev) (void)hipFree(d_gene_rev);
     free_lanes();
     if (have_events) {
@@ -146,8 +131,30 @@ struct gf_index {
   }
 };
 
+// Workspaces of the device-buffer entry points: one per (device, stream, kind), grow-only, owned
+// by the PROCESS, not by an index — in multi-CSV mode the index is rebuilt per CSV over a resident
+// read set (fusion_scan.rs:62-188), and a workspace that died with its index meant a multi-GB
+// hipFree + hipMalloc per CSV.  Calls on one stream run in order, so the next call may reuse the
+// buffers; launch sequences are serialised by the kind's mutex so that two host threads sharing a
+// stream cannot interleave their kernels.  (Stream-ordered hipMallocAsync/hipFreeAsync was tried
+// first: on the legacy default stream a free issued right after the launches raced with the kernels.)
+// gf_index_trim releases a device's workspaces; nothing is freed at process exit.
+struct Workspace { void* base = nullptr; size_t bytes = 0; };
+struct WsKey {
+  int device; hipStream_t st;
+  bool operator<(const WsKey& o) const { return device != o.device ? device < o.device : st < o.st; }
+};
+struct WsPool {
+  std::mutex mu;  // the map, and the launch sequences that use its buffers
+  std::map<WsKey, Workspace> ws;
+};
+static WsPool& ws_pool(bool pair) {
+  static WsPool* pools = new WsPool[2];  // (never destroyed: the HIP runtime may be gone by then)
+  return pools[pair ? 1 : 0];
+}
+
 static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** out, bool pair = false) {
-  gf_index::Workspace& W = pair ? mix->ws_pair[st] : mix->ws[st];  // caller holds ws_mu / pair_mu
+  Workspace& W = ws_pool(pair).ws[WsKey{mix->device, st}];  // caller holds the pool's mutex
   if (W.bytes < need) {
     if (W.base) {
       GF_HIP(hipStreamSynchronize(st));  // earlier calls on this stream may still use it
@@ -499,6 +506,33 @@ int gf_index_lookup(const gf_index* idx, const uint32_t* kmers, int64_t n, int32
 }
 
 // One span of a batch (n <= GF_SPAN_MAX reads): the kernels keep read indices in 32 bits.
+// Test/diagnostic (like gf_index_lookup): segment_mask of the device on caller-given masks.
+static int segment_mask_test_impl(const gf_index* idx, const uint8_t* masks, const int64_t* offsets, int64_t n,
+                                  const int64_t* gp1, const int64_t* gp2, int32_t* out_counts, gf_seqmatch* out_matches) {
+  const int64_t total = offsets[n];
+  DevBuf<uint8_t> d_m, d_c;
+  DevBuf<int64_t> d_o, d_g1, d_g2;
+  DevBuf<gf_seqmatch> d_out;
+  GF_HIP(d_m.alloc((size_t)total + 16)); GF_HIP(d_c.alloc((size_t)n)); GF_HIP(d_o.alloc((size_t)n + 1));
+  GF_HIP(d_g1.alloc((size_t)n)); GF_HIP(d_g2.alloc((size_t)n)); GF_HIP(d_out.alloc(2 * (size_t)n));
+  if (total > 0) GF_HIP(hipMemcpy(d_m.p, masks, (size_t)total, hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(d_o.p, offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(d_g1.p, gp1, (size_t)n * 8, hipMemcpyHostToDevice));
+  GF_HIP(hipMemcpy(d_g2.p, gp2, (size_t)n * 8, hipMemcpyHostToDevice));
+  GF_HIP(hipMemset(d_c.p, 0, (size_t)n));
+  GF_HIP(hipMemset(d_out.p, 0, 2 * (size_t)n * sizeof(gf_seqmatch)));
+  const int grid = (int)std::min<int64_t>(n, (int64_t)idx->n_cus * 8);
+  hipLaunchKernelGGL((gf_k_segment_mask_test<256>), dim3(grid), dim3(64), 0, 0, d_m.p, d_o.p, n, 0, d_g1.p, d_g2.p, d_c.p, d_out.p);
+  hipLaunchKernelGGL((gf_k_segment_mask_test<1024>), dim3(grid), dim3(64), 0, 0, d_m.p, d_o.p, n, 256, d_g1.p, d_g2.p, d_c.p, d_out.p);
+  hipLaunchKernelGGL((gf_k_segment_mask_test<4096>), dim3(grid), dim3(64), 0, 0, d_m.p, d_o.p, n, 1024, d_g1.p, d_g2.p, d_c.p, d_out.p);
+  GF_HIP(hipGetLastError());
+  std::vector<uint8_t> c8((size_t)n);
+  GF_HIP(hipMemcpy(c8.data(), d_c.p, (size_t)n, hipMemcpyDeviceToHost));
+  GF_HIP(hipMemcpy(out_matches, d_out.p, 2 * (size_t)n * sizeof(gf_seqmatch), hipMemcpyDeviceToHost));
+  for (int64_t r = 0; r < n; ++r) out_counts[r] = c8[(size_t)r];
+  return GF_OK;
+}
+
 static int map_span_device(const gf_index* idx, const uint8_t* bases, const int64_t* offsets, int64_t n,
                            int32_t max_read_len, uint8_t* counts, gf_seqmatch* matches, hipStream_t st, bool prof,
                            const int32_t* skip) {
@@ -515,7 +549,7 @@ static int map_span_device(const gf_index* idx, const uint8_t* bases, const int6
     // that covers the merged reads of 2 x 150 — and lists for the wave-per-read kernels of longer reads
     const int lmax = std::min<int>(max_read_len, 320);
     const int pw = lmax <= 160 ? 10 : (lmax <= 256 ? 16 : 20);
-    std::lock_guard<std::mutex> ws_lock(mix->ws_mu);  // held until this call's launches are queued
+    std::lock_guard<std::mutex> ws_lock(ws_pool(false).mu);  // held until this call's launches are queued
     const FlatPlan p = flat_plan(n, idx->n_cus, pw, max_read_len > lmax);
     void* ws_base = nullptr;
     int wrc = acquire_workspace(mix, st, p.bytes(), &ws_base);
@@ -608,6 +642,20 @@ static int map_reads_device_impl(const gf_index* idx, const void* d_bases, const
     mix->recorded = true;
   }
   return GF_OK;
+}
+
+int gf_segment_mask_test(const gf_index* idx, const uint8_t* masks, const int64_t* offsets, int64_t n,
+                         const int64_t* gp1, const int64_t* gp2, int32_t* out_counts, gf_seqmatch* out_matches) {
+  if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
+  if (n == 0) return GF_OK;
+  if (!offsets || !gp1 || !gp2 || !out_counts || !out_matches) return fail(GF_ERR_ARG, "null argument");
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t l = offsets[r + 1] - offsets[r];
+    if (l < 1 || l > GF_MAX_READ_LEN) return fail(GF_ERR_ARG, "mask length must be 1..GF_MAX_READ_LEN");
+  }
+  if (offsets[0] != 0 || !masks) return fail(GF_ERR_ARG, "masks must start at offset 0");
+  DeviceGuard guard(idx->device);
+  return segment_mask_test_impl(idx, masks, offsets, n, gp1, gp2, out_counts, out_matches);
 }
 
 int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
@@ -1362,7 +1410,7 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   const size_t o_rb = cv.take((size_t)retry_bytes_cap + 64), o_rq = cv.take((size_t)retry_bytes_cap + 64);
   const size_t o_cR = cv.take((size_t)retry_cap), o_mR = cv.take((size_t)retry_cap * 32);
 
-  std::lock_guard<std::mutex> lk(mix->pair_mu);  // held until this call's launches are queued
+  std::lock_guard<std::mutex> lk(ws_pool(true).mu);  // held until this call's launches are queued
   void* base = nullptr;
   int rc = acquire_workspace(mix, st, cv.off, &base, true);
   if (rc != GF_OK) return rc;
@@ -1482,11 +1530,12 @@ void gf_stream_close(gf_stream* s) {
     if (sl.st) {
       (void)hipEventDestroy(sl.done);
       // the mapping workspace cached for this stream goes with it
-      std::lock_guard<std::mutex> lk(s->ix->ws_mu);
-      auto it = s->ix->ws.find(sl.st);
-      if (it != s->ix->ws.end()) {
+      WsPool& P = ws_pool(false);
+      std::lock_guard<std::mutex> lk(P.mu);
+      auto it = P.ws.find(WsKey{s->ix->device, sl.st});
+      if (it != P.ws.end()) {
         if (it->second.base) (void)hipFree(it->second.base);
-        s->ix->ws.erase(it);
+        P.ws.erase(it);
       }
       (void)hipStreamDestroy(sl.st);
     }
@@ -1601,16 +1650,17 @@ int gf_index_trim(gf_index* idx) {
       if (L->pinned) { GF_HIP(hipHostFree(L->pinned)); L->pinned = nullptr; L->pinned_bytes = 0; }
     }
   }
-  std::lock_guard<std::mutex> l1(idx->pair_mu);
-  std::lock_guard<std::mutex> l2(idx->ws_mu);
-  for (auto* m : {&idx->ws, &idx->ws_pair})
-    for (auto& kv : *m)
-      if (kv.second.base) {
-        GF_HIP(hipStreamSynchronize(kv.first));  // calls queued on that stream may still use it
+  for (int k = 1; k >= 0; --k) {  // (lock order: pair pool, then map pool — as gf_scan_pairs_device takes them)
+    WsPool& P = ws_pool(k == 1);
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (auto& kv : P.ws)
+      if (kv.first.device == idx->device && kv.second.base) {
+        GF_HIP(hipStreamSynchronize(kv.first.st));  // calls queued on that stream may still use it
         GF_HIP(hipFree(kv.second.base));
         kv.second.base = nullptr;
         kv.second.bytes = 0;
       }
+  }
   return GF_OK;
 }
 

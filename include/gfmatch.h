@@ -106,10 +106,11 @@ void gf_index_free(gf_index* idx);
 int gf_index_info_get(const gf_index* idx, gf_index_info* out);
 
 /* Long-lived hosts: the library keeps grow-only device memory between calls — a workspace per
- * (index, stream) used by gf_map_reads_device / gf_scan_pairs_device (64-112 bytes per read of the
- * largest span mapped on that stream, at most 2^30 reads per span) and the arenas of the
- * host-buffer entry points.  gf_index_trim waits for the work queued on those streams and frees
- * them all (they grow again on demand); gf_index_free frees everything. */
+ * (device, stream) used by gf_map_reads_device / gf_scan_pairs_device (64-112 bytes per read of the
+ * largest span mapped on that stream, at most 2^30 reads per span; owned by the process so that it
+ * survives the index rebuilds of multi-CSV mode) and, per index, the arenas of the host-buffer entry
+ * points.  gf_index_trim waits for the work queued on those streams and frees them all for the
+ * index's device (they grow again on demand); gf_index_free frees what the index owns. */
 int gf_index_trim(gf_index* idx);
 
 /* Indexer.m_fusion_seq[c] (indexer.rs:77, :170; read by fusion_mapper.rs:230,
@@ -125,6 +126,13 @@ int64_t gf_index_fusion_seq(const gf_index* idx, int32_t contig, char* out, int6
  * position) order.  Host buffers. */
 int gf_index_lookup(const gf_index* idx, const uint32_t* kmers, int64_t n, int32_t* out_count,
                     int16_t* out_contig, int32_t* out_position);
+
+/* Test/diagnostic: segment_mask (indexer.rs:616-679) as the device computes it, on caller-given
+ * class masks (values 0..3, mask r = masks[offsets[r] .. offsets[r+1]), 1..GF_MAX_READ_LEN long,
+ * offsets[0] = 0) with gp1 / gp2 as the reference's i64 keys (indexer.rs:698-706).  out_counts[r] =
+ * segments returned (0..2), out_matches[2r + k] = them.  Host buffers. */
+int gf_segment_mask_test(const gf_index* idx, const uint8_t* masks, const int64_t* offsets, int64_t n,
+                         const int64_t* gp1, const int64_t* gp2, int32_t* out_counts, gf_seqmatch* out_matches);
 
 /* --- mapping ---------------------------------------------------------------
  * gf_map_reads replaces the per-pack loop over Indexer::map_read

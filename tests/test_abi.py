@@ -33,9 +33,19 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.gf_version()
 
 
+def test_integration_doc_binds_every_entry_point():
+    """INTEGRATION.md's Rust `extern "C"` block names every function include/gfmatch.h declares."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index('extern "C" {'):doc.index("pub fn last_error()")]
+    bound = set(re.findall(r"pub fn (gf_[a-z0-9_]+)\(", block))
+    missing = [n for n in _declared_functions() if n not in bound]
+    assert not missing, missing
+
+
 def test_struct_layouts_match_header():
     from genefuserust_amd import _lib
-    assert C.sizeof(_lib.GfSeqMatch) == 16 and C.sizeof(_lib.GfHit) == 48
+    assert C.sizeof(_lib.GfSeqMatch) == 16 and C.sizeof(_lib.GfHit) == 48 and C.sizeof(_lib.GfPairHit) == 64
+    assert _lib.PAIR_HIT_DTYPE.itemsize == 64
     assert _lib.SEQMATCH_DTYPE.itemsize == 16 and _lib.HIT_DTYPE.itemsize == 48
     assert C.sizeof(_lib.GfOptions) == 32
     assert C.sizeof(_lib.GfIndexInfo) == 88

@@ -461,3 +461,52 @@ def test_single_read_calls_are_stable(branch_index, golden):
             got = branch_index.map_read(c["read"])
             flat = [(m.seq_start, m.seq_end, m.start_gp.contig, m.start_gp.position) for m in got]
             assert flat == [tuple(m) for m in c["expect"]], (rep, c["label"])
+
+
+def test_segment_mask_device_vs_reference_scan_on_random_masks(branch_index, oracle):
+    """The device form of segment_mask (heads / targets as bit masks, gf_map_kernels.h) against the
+    reference's sequential scan (indexer.rs:616-679, oracle: orc_segment_mask) on masks that no read
+    has to produce: random class runs with every gap length around ALLOWED_GAP = 10, higher classes
+    cutting runs, runs starting at the last base, ties between equally long runs, lengths 1..4096."""
+    from genefuserust_amd import _lib
+    rng = np.random.default_rng(2024)
+    masks, want = [], []
+    lens = [1, 2, 21, 22, 23, 63, 64, 65, 127, 128, 129, 150, 255, 256, 257, 272, 320, 1023, 1024, 1025, 4095, 4096]
+    lens += [int(x) for x in rng.integers(20, 400, size=1500)] + [int(x) for x in rng.integers(400, 4097, size=120)]
+    for L in lens:
+        style = int(rng.integers(0, 5))
+        m = np.zeros(L, dtype=np.uint8)
+        if style == 0:     # i.i.d. classes
+            m = rng.integers(0, 4, size=L).astype(np.uint8)
+        elif style == 4:   # one class everywhere, or nothing
+            m[:] = int(rng.integers(0, 4))
+        else:              # runs of a class separated by gaps of 0..14 low-class positions
+            p = 0
+            while p < L:
+                run = int(rng.integers(1, 60 if style < 3 else 12))
+                cls = int(rng.choice([2, 3, 3, 2, 1])) if style != 2 else int(rng.choice([2, 3]))
+                m[p:p + run] = cls
+                p += run
+                gap = int(rng.integers(0, 15))
+                g = min(gap, L - p)
+                if g > 0:
+                    m[p:p + g] = rng.integers(0, 2, size=g)
+                p += gap
+            if rng.random() < 0.3:
+                m[L - 1] = int(rng.choice([2, 3]))   # a run beginning at the last base is never seen (:635-640)
+        masks.append(m)
+    gp1 = np.array([oracle.gp_to_i64(int(c), int(p)) for c, p in zip(rng.integers(0, 30, len(masks)), rng.integers(-5000, 5000, len(masks)))], dtype=np.int64)
+    gp2 = np.array([oracle.gp_to_i64(int(c), int(p)) for c, p in zip(rng.integers(0, 30, len(masks)), rng.integers(-5000, 5000, len(masks)))], dtype=np.int64)
+    for m, a, b in zip(masks, gp1, gp2):
+        want.append(oracle.segment_mask(m, oracle.i64_to_gp(int(a)), oracle.i64_to_gp(int(b))))
+    flat = np.concatenate(masks)
+    offs = np.zeros(len(masks) + 1, dtype=np.int64)
+    np.cumsum([m.size for m in masks], out=offs[1:])
+    counts = np.zeros(len(masks), dtype=np.int32)
+    out = np.zeros((len(masks), 2), dtype=_lib.SEQMATCH_DTYPE)
+    _lib.check(_lib.lib().gf_segment_mask_test(branch_index._handle(), flat.ctypes.data, offs.ctypes.data, len(masks),
+                                               gp1.ctypes.data, gp2.ctypes.data, counts.ctypes.data, out.ctypes.data))
+    got = matches_to_tuples(counts, out)
+    bad = [k for k in range(len(masks)) if got[k] != want[k]]
+    assert not bad, (len(bad), bad[0], got[bad[0]], want[bad[0]], masks[bad[0]].tolist())
+    assert sum(1 for w in want if len(w) == 2) > 300 and sum(1 for w in want if len(w) == 1) > 100

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Pairs per second from FASTQ text resident in HBM to the hit list, on one MI355X: records
+(gf_fastq_index_device + gf_fastq_gather_device, R1 and R2) -> ONE gf_scan_pairs_device call
+(fast_merge, merged-or-R1+R2 mapping, reverse-complement retries, ordered compaction of the
+matched reads: the policy of PairEndScanner::scan_pair_end, pescanner.rs:427-518) — and, as a
+separate figure, the host-side tail (make_match / calc_distance per hit) that follows.
+
+Synthetic pairs per SURVEY.md §8(d) (synth.make_pairs: fragments N(300,30) cut from the
+druggable-shaped genes, PANEL mix, junction fragments planted).  One JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from tools.bench_frontend import make_text, timed  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=10_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--shape", default="IDX-D")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--check", type=int, default=3000)
+    a = ap.parse_args()
+    from genefuserust_amd import FusionMapper, Indexer, synth
+    from genefuserust_amd.fastq import fastq_cut_device
+    from genefuserust_amd.read_pair import finish_pair_hits, scan_pairs_device
+    dev = torch.device("cuda", 0)
+    genes = synth.make_geneset(a.shape)
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    n, L = a.pairs, a.read_len
+    pr = synth.make_pairs(genes, n, read_len=L, seed=20240301, device="cuda")
+    t1 = make_text(pr.l_bases, pr.l_quals, n, L, 1, dev)
+    t2 = make_text(pr.r_bases, pr.r_quals, n, L, 2, dev)
+    kinds = pr.kinds
+    del pr
+    torch.cuda.synchronize()
+    ms_cut1, b1 = timed(lambda: fastq_cut_device(ix, t1), a.steps, a.warmup)
+    ms_cut2, b2 = timed(lambda: fastq_cut_device(ix, t2), a.steps, a.warmup)
+    assert b1.n_records == b2.n_records == n
+    ms_scan, res = timed(lambda: scan_pairs_device(ix, b1.bases, b1.quals, b1.offsets, b2.bases, b2.quals, b2.offsets, L),
+                         a.steps, a.warmup)
+    rec, hb, hq, tot = res.download()
+    assert tot["overflow"] == 0, tot
+    fm = FusionMapper(ix)
+    t0 = time.perf_counter()
+    done = finish_pair_hits(fm, rec, hb, hq)
+    tail_s = time.perf_counter() - t0
+    # parity sample: the records of the first pairs against the oracle-driven policy
+    from oracle import oracle_py
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from tests.test_pair_pipeline import _reference_policy
+    k = min(a.check, n)
+    ox = oracle_py.OracleIndexer(genes.seqs)
+    o1, o2 = b1.offsets[:k + 1].cpu().numpy(), b2.offsets[:k + 1].cpu().numpy()
+    lb, lq = b1.bases[:o1[-1]].cpu().numpy().tobytes(), b1.quals[:o1[-1]].cpu().numpy().tobytes()
+    rb, rq = b2.bases[:o2[-1]].cpu().numpy().tobytes(), b2.quals[:o2[-1]].cpu().numpy().tobytes()
+    pairs = [(lb[o1[i]:o1[i + 1]], lq[o1[i]:o1[i + 1]], rb[o2[i]:o2[i + 1]], rq[o2[i]:o2[i + 1]]) for i in range(k)]
+    want, _ = _reference_policy(oracle_py, ox, genes.reversed_flags, pairs)
+    flat = [(p, w) for p, ws in enumerate(want) for w in ws]
+    got = [h for h in rec if int(h["pair_id"]) < k]
+    bad = int(len(got) != len(flat))
+    for h, (p, (source, on_rc, m_rev, seq, qual, rm)) in zip(got, flat):
+        o, ln = int(h["seq_offset"]), int(h["read_len"])
+        bad += not (int(h["pair_id"]) == p and int(h["source"]) == source and bool(h["flags"] & 1) == on_rc and
+                    hb[o:o + ln] == seq and hq[o:o + ln] == qual)
+    total = ms_cut1 + ms_cut2 + ms_scan
+    text_bytes = int(t1.numel() + t2.numel())
+    print(json.dumps({
+        "metric": "read pairs per second from FASTQ text in HBM to the hit list (records + scan_pair_end policy in one device call)",
+        "value": n / (total / 1e3), "unit": "pairs/s", "pairs": n, "read_len": L, "index_shape": a.shape,
+        "stage_ms": {"fastq_cut_R1": round(ms_cut1, 3), "fastq_cut_R2": round(ms_cut2, 3), "scan_pairs_device": round(ms_scan, 3)},
+        "scan_pairs_only_pairs_per_s": n / (ms_scan / 1e3),
+        "totals": tot, "junction_pairs": int((kinds == 2).sum()),
+        "host_tail": {"hits": len(done), "seconds": round(tail_s, 4), "hits_per_s": len(done) / tail_s if tail_s else None,
+                      "note": "make_match + calc_distance per hit through the C ABI from Python, one thread"},
+        "text_bytes": text_bytes, "text_GBps": text_bytes / (total / 1e3) / 1e9,
+        "parity": {"checked_pairs": k, "records_expected": len(flat), "mismatches": bad}}))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -10,10 +10,17 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity"
+# BENCH_ARGS: extra bench.py arguments (e.g. "--config 2 --pairs 10000000" for IDX-C at 20 M reads);
+# PMC_SETS: "all" (default) or "traffic" (FETCH/WRITE/TCC only)
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-h2d ${BENCH_ARGS:-}"
+PMC_SETS=${PMC_SETS:-all}
 echo "== kernel trace ==" 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.log 2>&1 || { echo trace failed; tail -20 $OUT/trace_bench.log; exit 1; }
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum")
+if [ "$PMC_SETS" = "all" ]; then
+  SETS+=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE")
+fi
+for pmc in "${SETS[@]}"; do
   name=$(echo $pmc | tr ' ' '_' | cut -c1-40)
   echo "== pmc $pmc =="
   rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_$name -o pmc -- $BENCH > $OUT/pmc_${name}.log 2>&1 || { echo "pmc $pmc failed"; tail -5 $OUT/pmc_${name}.log; }
