@@ -223,6 +223,23 @@ __device__ __forceinline__ uint32_t gf_stage_read(GfMapSmem<LCAP>& S, const uint
   return sh;
 }
 
+// ---- 1p. the same from the packed form of the batch (gf_pack_bases_device: word c of g_pk / g_iv =
+// bases 16c .. 16c+15 of the whole stream): a copy; returns the read's phase inside its first word ----
+template <int LCAP>
+__device__ __forceinline__ uint32_t gf_stage_read_packed(GfMapSmem<LCAP>& S, const uint32_t* __restrict__ g_pk,
+                                                         const uint16_t* __restrict__ g_iv, int64_t off0, int L,
+                                                         int lane) {
+  const uint32_t sh = (uint32_t)(off0 & 15);
+  const int64_t c0 = off0 >> 4;
+  const int nw = (int)((sh + (uint32_t)L + 15u) >> 4);
+  uint16_t* inv_h = (uint16_t*)S.inv;
+  for (int t = lane; t < nw; t += 64) {
+    S.codes[t] = g_pk[c0 + t];
+    inv_h[t] = g_iv[c0 + t];
+  }
+  return sh;
+}
+
 // append up to 5 votes per lane to the LDS list (ballot + mbcnt prefix sums)
 template <int LCAP>
 __device__ __forceinline__ int gf_append_votes(GfMapSmem<LCAP>& S, int nvotes, int nv, const uint32_t v[5]) {

@@ -208,9 +208,13 @@ __device__ __forceinline__ uint32_t gf_window_mask(int nwin, int k) {
 #ifndef GF_SVS_WAVES_PER_SIMD
 #define GF_SVS_WAVES_PER_SIMD 4  // (four blocks per CU run anyway, see launch_flat: the registers of six are not needed)
 #endif
-template <int PW>
+// PACKED: the reads arrive as the 2-bit + bad-bit form of the whole `bases` stream (gf_pack_bases_device:
+// word c of g_pk / g_iv = bases 16c .. 16c+15, `offsets` still count bases) — a tile is then copied,
+// 6 bytes per 16 bases instead of 16, and nothing is converted.
+template <int PW, bool PACKED = false>
 __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_k_seedverify_stream(
-    GfTable T, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets, int64_t n, int lmax,
+    GfTable T, const uint8_t* __restrict__ bases, const uint32_t* __restrict__ g_pk,
+    const uint16_t* __restrict__ g_iv, const int64_t* __restrict__ offsets, int64_t n, int lmax,
     int batch_max, uint8_t* __restrict__ counts, GfPipeEntryW<PW>* __restrict__ list_b,
     unsigned int* __restrict__ blk_cnt, int64_t per_block, uint32_t* __restrict__ list_long,
     unsigned int* __restrict__ ctr) {
@@ -245,8 +249,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       // the loads in the global address space with a scalar base).
       const int64_t base_off = offsets[r0];
       const uint8_t* p0 = bases + base_off;
-      const uint32_t mis = (uint32_t)((uintptr_t)p0 & 15u);
+      const uint32_t mis = PACKED ? (uint32_t)(base_off & 15) : (uint32_t)((uintptr_t)p0 & 15u);
       const uint4* src = (const uint4*)(p0 - mis);
+      const int64_t c0 = base_off >> 4;  // (PACKED) first chunk of the tile in the packed stream
       const int64_t r = r0 + lane;
       int64_t off0 = 0, off1 = 0;
       if (r < g1) {
@@ -259,7 +264,24 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       if (oversize) nfit = 1;
       gf_wave_lds_sync();  // the previous tile's LDS reads are done
       const uint32_t chunks = oversize ? 0u : (uint32_t)((offsets[r0 + nfit] - base_off) + mis + 15) >> 4;
-      if (chunks > 0) {  // (empty reads only: nothing to stage)
+      if (PACKED && chunks > 0) {
+        uint32_t qp[NLOAD], qi[NLOAD];
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {  // all of the tile's loads in flight together
+          const uint32_t c = (uint32_t)lane + 64u * (uint32_t)k;
+          const int64_t cc = c0 + (int64_t)(c < chunks ? c : chunks - 1);
+          qp[k] = __builtin_nontemporal_load(g_pk + cc);
+          qi[k] = __builtin_nontemporal_load(g_iv + cc);
+        }
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+          const uint32_t c = (uint32_t)lane + 64u * (uint32_t)k;
+          if (c < chunks) {
+            s_pk[c] = qp[k];
+            ((uint16_t*)s_iv)[c] = (uint16_t)qi[k];
+          }
+        }
+      } else if (chunks > 0) {  // (empty reads only: nothing to stage)
         uint4 q[NLOAD];
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {  // all of the tile's loads in flight together
@@ -781,9 +803,10 @@ __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPip
 }
 
 // ---- K_full: the exact wave-per-read kernel over a list of read indices ----
-template <int LCAP, int WAVES>
+template <int LCAP, int WAVES, bool PACKED = false>
 __global__ __launch_bounds__(WAVES * 64, LCAP <= 256 ? 8 : (LCAP <= 1024 ? 3 : 1)) void gf_k_map_reads_list(
-    GfTable T, const uint8_t* __restrict__ bases, const int64_t* __restrict__ offsets,
+    GfTable T, const uint8_t* __restrict__ bases, const uint32_t* __restrict__ g_pk,
+    const uint16_t* __restrict__ g_iv, const int64_t* __restrict__ offsets,
     const uint32_t* __restrict__ list, int64_t stride, const unsigned int* __restrict__ n_list,
     uint8_t* __restrict__ counts, gf_seqmatch* __restrict__ matches) {
   __shared__ GfMapSmem<LCAP> smem[WAVES];
@@ -796,9 +819,39 @@ __global__ __launch_bounds__(WAVES * 64, LCAP <= 256 ? 8 : (LCAP <= 1024 ? 3 : 1
     const int64_t off0 = offsets[r];
     const int L = (int)(offsets[r + 1] - off0);
     gf_wave_lds_sync();
-    const uint32_t sh = gf_stage_read<LCAP>(S, bases + off0, L, lane);
+    uint32_t sh;
+    if constexpr (PACKED) sh = gf_stage_read_packed<LCAP>(S, g_pk, g_iv, off0, L, lane);
+    else sh = gf_stage_read<LCAP>(S, bases + off0, L, lane);
     gf_wave_lds_sync();
     const int nvotes = gf_first_pass_probe_all<LCAP>(T, S, L, sh, lane);
     gf_finish_read<LCAP>(T, S, L, sh, nvotes, lane, r, counts, matches);
+  }
+}
+
+// ---- ASCII bases -> the packed form the PACKED kernels take: thread per 16-base chunk ----
+// pk[c] = 2-bit codes of bases 16c .. 16c+15 (base j in bits 2j, 2j+1; gf_table.h), iv[c] bit j = that
+// base is not one of A C G T (bases at or beyond n_bases count as such).
+__global__ __launch_bounds__(256) void gf_k_pack_bases(const uint8_t* __restrict__ bases, int64_t n_bases,
+                                                       uint32_t* __restrict__ pk, uint16_t* __restrict__ iv,
+                                                       int64_t n_chunks) {
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b0 = 16 * c;
+    uint4 q = make_uint4(0, 0, 0, 0);
+    uint32_t tail_bad = 0;
+    if (b0 + 16 <= n_bases) {
+      const gf_u32x4 t = __builtin_nontemporal_load((const gf_u32x4*)(bases + b0));  // (any byte alignment)
+      q = make_uint4(t.x, t.y, t.z, t.w);
+    } else {
+      uint32_t w[4] = {0, 0, 0, 0};
+      for (int j = 0; j < 16; ++j) {
+        if (b0 + j < n_bases) w[j >> 2] |= (uint32_t)bases[b0 + j] << (8 * (j & 3));
+        else tail_bad |= 1u << j;
+      }
+      q = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    uint32_t code32, bad16;
+    gf_convert16(q, code32, bad16);
+    pk[c] = code32;
+    iv[c] = (uint16_t)(bad16 | tail_bad);
   }
 }

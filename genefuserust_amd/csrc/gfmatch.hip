@@ -214,17 +214,26 @@ static FlatWs flat_carve(uint8_t* wp, const FlatPlan& p) {
 // ev[0..4] (optional): stage boundaries.  lmax = longest read of the flat kernels in this call,
 // batch_max = the caller's limit: reads in between go to the wave-per-read kernels of the
 // longer classes (LDS footprints for 1024 and 4096 bases) through a list.
-template <int PW>
-static int launch_flat(const gf_index* idx, const GfTable& T, hipStream_t st, const uint8_t* bases, const int64_t* offsets,
+// the reads of a call: ASCII bases, or their packed form (gf_pack_bases_device); offsets count bases either way
+struct ReadSrc {
+  const uint8_t* bases = nullptr;
+  const uint32_t* pk = nullptr;
+  const uint16_t* iv = nullptr;
+  bool packed() const { return pk != nullptr; }
+};
+
+template <int PW, bool PACKED>
+static int launch_flat(const gf_index* idx, const GfTable& T, hipStream_t st, const ReadSrc& src, const int64_t* offsets,
                        int64_t n, int lmax, int batch_max, uint8_t* counts, gf_seqmatch* matches, const FlatWs& w,
                        const FlatPlan& p, hipEvent_t* ev) {
+  const uint8_t* bases = src.bases;
   GF_HIP(hipMemsetAsync(w.ctr, 0, 64, st));
   if (ev) GF_HIP(hipEventRecord(ev[0], st));
   // Seed+verify is bound by the line fills of its CU's L1, not by waves in flight: four blocks
   // per CU (40 KB of LDS each, padded with dynamic LDS) measured 2.5 % faster than six.
   size_t pad_lds = PW == 10 ? 24000 : 0;
   if (const char* e = getenv("GF_SV_PAD_LDS")) pad_lds = (size_t)atoi(e);  // experiments
-  hipLaunchKernelGGL((gf_k_seedverify_stream<PW>), dim3(p.nblk), dim3(256), pad_lds, st, T, bases, offsets, n,
+  hipLaunchKernelGGL((gf_k_seedverify_stream<PW, PACKED>), dim3(p.nblk), dim3(256), pad_lds, st, T, bases, src.pk, src.iv, offsets, n,
                      lmax, batch_max, counts, (GfPipeEntryW<PW>*)w.list_b, w.blk_cnt, p.per_block, w.list_long, w.ctr);
   if (ev) GF_HIP(hipEventRecord(ev[1], st));
   // a filter that does not fit an XCD's L2 (bloom_in_l2 == 1) is asked part by part, so that the part
@@ -245,16 +254,16 @@ static int launch_flat(const gf_index* idx, const GfTable& T, hipStream_t st, co
                      (const GfPipeEntryW<PW>*)w.list_b, survivors, p.per_block, counts, w.list_c, w.ctr);
   if (ev) GF_HIP(hipEventRecord(ev[3], st));
   if (PW <= 16)
-    hipLaunchKernelGGL((gf_k_map_reads_list<256, 4>), dim3(idx->n_cus * 8), dim3(256), 0, st, T, bases, offsets,
+    hipLaunchKernelGGL((gf_k_map_reads_list<256, 4, PACKED>), dim3(idx->n_cus * 8), dim3(256), 0, st, T, bases, src.pk, src.iv, offsets,
                        w.list_c, (int64_t)1, w.ctr + 1, counts, matches);
   else  // survivors of up to 320 bases
-    hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4>), dim3(idx->n_cus * 4), dim3(256), 0, st, T, bases,
+    hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4, PACKED>), dim3(idx->n_cus * 4), dim3(256), 0, st, T, bases, src.pk, src.iv,
                        offsets, w.list_c, (int64_t)1, w.ctr + 1, counts, matches);
   if (batch_max > lmax) {
-    hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4>), dim3(idx->n_cus * 4), dim3(256), 0, st, T, bases,
+    hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4, PACKED>), dim3(idx->n_cus * 4), dim3(256), 0, st, T, bases, src.pk, src.iv,
                        offsets, w.list_long, (int64_t)1, w.ctr + 2, counts, matches);
     if (batch_max > 1024)
-      hipLaunchKernelGGL((gf_k_map_reads_list<4096, 2>), dim3(idx->n_cus * 4), dim3(128), 0, st, T, bases,
+      hipLaunchKernelGGL((gf_k_map_reads_list<4096, 2, PACKED>), dim3(idx->n_cus * 4), dim3(128), 0, st, T, bases, src.pk, src.iv,
                          offsets, w.list_long + (n - 1), (int64_t)-1, w.ctr + 3, counts, matches);
   }
   GF_HIP(hipGetLastError());
@@ -533,10 +542,13 @@ static int segment_mask_test_impl(const gf_index* idx, const uint8_t* masks, con
   return GF_OK;
 }
 
-static int map_span_device(const gf_index* idx, const uint8_t* bases, const int64_t* offsets, int64_t n,
+static int map_span_device(const gf_index* idx, const ReadSrc& src, const int64_t* offsets, int64_t n,
                            int32_t max_read_len, uint8_t* counts, gf_seqmatch* matches, hipStream_t st, bool prof,
                            const int32_t* skip) {
   gf_index* mix = const_cast<gf_index*>(idx);
+  const uint8_t* bases = src.bases;
+  if (src.packed() && idx->map_variant != 0)
+    return fail(GF_ERR_ARG, "packed reads are taken by the flat pipeline only (gf_set_map_variant 0)");
   GfTable T = idx->table;
   T.skip = skip;  // (per call: the index itself stays read-only)
   // persistent grid: enough waves to fill every CU, reads interleaved across waves
@@ -556,9 +568,14 @@ static int map_span_device(const gf_index* idx, const uint8_t* bases, const int6
     if (wrc != GF_OK) return wrc;
     const FlatWs w = flat_carve((uint8_t*)ws_base, p);
     hipEvent_t* ev = prof ? mix->ev_stage : nullptr;
-    wrc = pw == 10   ? launch_flat<10>(idx, T, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
-          : pw == 16 ? launch_flat<16>(idx, T, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
-                     : launch_flat<20>(idx, T, st, bases, offsets, n, lmax, max_read_len, counts, matches, w, p, ev);
+    if (src.packed())
+      wrc = pw == 10   ? launch_flat<10, true>(idx, T, st, src, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
+            : pw == 16 ? launch_flat<16, true>(idx, T, st, src, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
+                       : launch_flat<20, true>(idx, T, st, src, offsets, n, lmax, max_read_len, counts, matches, w, p, ev);
+    else
+      wrc = pw == 10   ? launch_flat<10, false>(idx, T, st, src, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
+            : pw == 16 ? launch_flat<16, false>(idx, T, st, src, offsets, n, lmax, max_read_len, counts, matches, w, p, ev)
+                       : launch_flat<20, false>(idx, T, st, src, offsets, n, lmax, max_read_len, counts, matches, w, p, ev);
     if (wrc != GF_OK) return wrc;
     if (prof) mix->stages_recorded = true;
   } else {
@@ -605,7 +622,7 @@ static int64_t span_max_reads() {
 
 static int map_reads_device_impl(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
                                  int32_t max_read_len, void* d_counts, void* d_matches, void* stream,
-                                 const int32_t* d_skip) {
+                                 const int32_t* d_skip, const void* d_pk = nullptr, const void* d_iv = nullptr) {
   if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
   if (n == 0) return GF_OK;
   if (!d_offsets || !d_counts || !d_matches) return fail(GF_ERR_ARG, "null device pointer");
@@ -624,7 +641,10 @@ static int map_reads_device_impl(const gf_index* idx, const void* d_bases, const
     }
     GF_HIP(hipEventRecord(mix->ev0, st));
   }
-  const uint8_t* bases = (const uint8_t*)d_bases;
+  ReadSrc src;
+  src.bases = (const uint8_t*)d_bases;
+  src.pk = (const uint32_t*)d_pk;
+  src.iv = (const uint16_t*)d_iv;
   const int64_t* offsets = (const int64_t*)d_offsets;
   uint8_t* counts = (uint8_t*)d_counts;
   gf_seqmatch* matches = (gf_seqmatch*)d_matches;
@@ -632,7 +652,7 @@ static int map_reads_device_impl(const gf_index* idx, const void* d_bases, const
   for (int64_t s0 = 0; s0 < n; s0 += span) {
     const int64_t ns = std::min(span, n - s0);
     // offsets are absolute positions in `bases`: a span is the same call on a later part of the arrays
-    const int rc = map_span_device(idx, bases, offsets + s0, ns, max_read_len, counts + s0, matches + 2 * s0, st, prof,
+    const int rc = map_span_device(idx, src, offsets + s0, ns, max_read_len, counts + s0, matches + 2 * s0, st, prof,
                                    d_skip ? d_skip + s0 : nullptr);
     if (rc != GF_OK) return rc;
   }
@@ -656,6 +676,26 @@ int gf_segment_mask_test(const gf_index* idx, const uint8_t* masks, const int64_
   if (offsets[0] != 0 || !masks) return fail(GF_ERR_ARG, "masks must start at offset 0");
   DeviceGuard guard(idx->device);
   return segment_mask_test_impl(idx, masks, offsets, n, gp1, gp2, out_counts, out_matches);
+}
+
+int64_t gf_packed_chunks(int64_t n_bases) { return n_bases < 0 ? 0 : (n_bases + 15) / 16 + 4; }
+
+int gf_pack_bases_device(const gf_index* idx, const void* d_bases, int64_t n_bases, void* d_pk, void* d_iv, void* stream) {
+  if (!idx || n_bases < 0) return fail(GF_ERR_ARG, "null index or negative size");
+  if (!d_pk || !d_iv || (n_bases > 0 && !d_bases)) return fail(GF_ERR_ARG, "null device pointer");
+  DeviceGuard guard(idx->device);
+  const int64_t chunks = gf_packed_chunks(n_bases);  // (the padding chunks are written too: all "bad")
+  const int grid = (int)std::min<int64_t>((chunks + 255) / 256, (int64_t)idx->n_cus * 32);
+  hipLaunchKernelGGL(gf_k_pack_bases, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_bases, n_bases,
+                     (uint32_t*)d_pk, (uint16_t*)d_iv, chunks);
+  GF_HIP(hipGetLastError());
+  return GF_OK;
+}
+
+int gf_map_reads_packed_device(const gf_index* idx, const void* d_pk, const void* d_iv, const void* d_offsets, int64_t n,
+                               int32_t max_read_len, void* d_counts, void* d_matches, void* stream) {
+  if (n > 0 && (!d_pk || !d_iv)) return fail(GF_ERR_ARG, "null packed stream");
+  return map_reads_device_impl(idx, nullptr, d_offsets, n, max_read_len, d_counts, d_matches, stream, nullptr, d_pk, d_iv);
 }
 
 int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,

@@ -374,6 +374,32 @@ class Indexer:
                                                   int(max_read_len), counts.data_ptr(), matches.data_ptr(), st))
         return counts, matches
 
+    def pack_bases_device(self, bases, stream=None):
+        """The 2-bit + bad-bit form of a whole ``bases`` buffer (gf_pack_bases_device): (pk int32, iv int16)
+        tensors; reads are then given by the same offsets.  Worth it when the reads are mapped more than once."""
+        import torch
+        L = _lib.lib()
+        nb = bases.numel()
+        ch = int(L.gf_packed_chunks(nb))
+        pk = torch.empty(ch, dtype=torch.int32, device=bases.device)
+        iv = torch.empty(ch, dtype=torch.int16, device=bases.device)
+        st = torch.cuda.current_stream(bases.device).cuda_stream if stream is None else stream
+        _lib.check(L.gf_pack_bases_device(self._handle(), bases.data_ptr(), nb, pk.data_ptr(), iv.data_ptr(), st))
+        return pk, iv
+
+    def map_reads_packed_device(self, pk, iv, offsets, max_read_len: int, counts=None, matches=None, stream=None):
+        """Indexer.map_reads_device on the packed form of the reads (same offsets, same results)."""
+        import torch
+        n = offsets.numel() - 1
+        if counts is None:
+            counts = torch.empty(max(n, 1), dtype=torch.uint8, device=pk.device)
+        if matches is None:
+            matches = torch.empty((max(n, 1), 2, 4), dtype=torch.int32, device=pk.device)
+        st = torch.cuda.current_stream(pk.device).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().gf_map_reads_packed_device(self._handle(), pk.data_ptr(), iv.data_ptr(), offsets.data_ptr(), n,
+                                                         int(max_read_len), counts.data_ptr(), matches.data_ptr(), st))
+        return counts, matches
+
     def compact_hits_device(self, counts, matches, n: int, read_id_base: int = 0, cap: Optional[int] = None,
                             stream=None):
         """Ordered compaction on the device; returns (hits int64[cap, 6] view of gf_hit, n_hits tensor)."""

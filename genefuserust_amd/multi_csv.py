@@ -56,6 +56,7 @@ def scan_multi_csv(genesets: Sequence, bases, offsets, max_read_len: int, rank: 
     from .indexer import Indexer
     n = offsets.numel() - 1
     out: Dict[int, object] = {}
+    packed = None   # the reads are mapped once per CSV: converted to the kernels' 2-bit form once, by the first index
     for job in plan_multi_csv(len(genesets), n, rank, world):
         seqs, rev = genesets[job.csv]
         ix = Indexer.from_gene_slices(seqs, rev, device=device)
@@ -64,7 +65,9 @@ def scan_multi_csv(genesets: Sequence, bases, offsets, max_read_len: int, rank: 
             if on_index is not None:
                 on_index(job.csv, ix)
             m = job.hi - job.lo
-            counts, matches = ix.map_reads_device(bases, offsets[job.lo:job.hi + 1], max_read_len)
+            if packed is None:
+                packed = ix.pack_bases_device(bases)
+            counts, matches = ix.map_reads_packed_device(packed[0], packed[1], offsets[job.lo:job.hi + 1], max_read_len)
             hits, n_hits = ix.compact_hits_device(counts, matches, m, read_id_base=job.lo, cap=max(m // 8, 4096))
             if len(job.group) > 1:
                 merged = allgather_hits(hits, n_hits, group=None if groups is None else groups[job.group])

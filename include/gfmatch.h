@@ -164,6 +164,20 @@ int gf_map_reads_hits(const gf_index* idx, const char* bases, const int64_t* off
 int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
                         int32_t max_read_len, void* d_counts, void* d_matches, void* stream);
 
+/* --- packed hand-over ---------------------------------------------------------------------------
+ * The mapping kernels work on 2 bits per base + 1 "not A/C/G/T" bit; with ASCII input they convert
+ * while they stage.  A host that maps the same reads more than once (multi-CSV mode: one index per
+ * CSV over a resident read set, fusion_scan.rs:62-188) or produces the reads on the device can hand
+ * over that form instead: gf_pack_bases_device converts a whole `bases` buffer (chunk c of d_pk
+ * (uint32) / d_iv (uint16) = bases 16c .. 16c+15 of the buffer; gf_packed_chunks(n_bases) elements
+ * each), and gf_map_reads_packed_device maps reads given by the SAME offsets (they count bases) —
+ * results identical to gf_map_reads_device on the ASCII buffer; 6 bytes fetched per 16 bases
+ * instead of 16. */
+int64_t gf_packed_chunks(int64_t n_bases);
+int gf_pack_bases_device(const gf_index* idx, const void* d_bases, int64_t n_bases, void* d_pk, void* d_iv, void* stream);
+int gf_map_reads_packed_device(const gf_index* idx, const void* d_pk, const void* d_iv, const void* d_offsets, int64_t n,
+                               int32_t max_read_len, void* d_counts, void* d_matches, void* stream);
+
 /* Ordered compaction of the dense result (device): writes gf_hit records for the
  * reads with count 1..2, ascending read index, to d_hits (capacity hits_cap
  * records) and the total to *d_n_hits (int64 on device).  d_workspace must hold

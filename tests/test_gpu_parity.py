@@ -510,3 +510,66 @@ def test_segment_mask_device_vs_reference_scan_on_random_masks(branch_index, ora
     bad = [k for k in range(len(masks)) if got[k] != want[k]]
     assert not bad, (len(bad), bad[0], got[bad[0]], want[bad[0]], masks[bad[0]].tolist())
     assert sum(1 for w in want if len(w) == 2) > 300 and sum(1 for w in want if len(w) == 1) > 100
+
+
+def _dense_equal(a, b, n):
+    ca, ma = a
+    cb, mb = b
+    import torch
+    assert torch.equal(ca[:n], cb[:n])
+    k = ca[:n].to(torch.int64)
+    valid = (torch.arange(2, device=ca.device)[None, :] < k[:, None])[:, :, None]
+    assert torch.equal(ma[:n] * valid, mb[:n] * valid)
+
+
+def test_packed_hand_over_equals_ascii(branch_index, golden, gpu_device):
+    """gf_pack_bases_device + gf_map_reads_packed_device return what gf_map_reads_device returns on the
+    ASCII buffer: golden branch cases with every length class (flat kernels, 1024- and 4096-base lists),
+    every phase of the first read inside its 16-base chunk, N / lower-case bases, empty reads."""
+    import torch
+    from genefuserust_amd.synth import ragged_batch
+    reads = [c["read"].encode() for c in golden["cases"]]
+    reads += [reads[0] * 3, (reads[3] + reads[4]) * 4, b"", b"acgtnACGTN" * 20, b"N" * 70]
+    for lead in (0, 1, 5, 15, 16, 23):
+        bases, offsets = ragged_batch(reads)
+        bases = np.concatenate([np.frombuffer(b"T" * lead, dtype=np.uint8), bases])
+        offsets = offsets + lead
+        d_b, d_o = torch.from_numpy(bases).cuda(), torch.from_numpy(offsets).cuda()
+        pk, iv = branch_index.pack_bases_device(d_b)
+        for lcap in (270, 1024, 4096):
+            a = branch_index.map_reads_device(d_b, d_o, lcap)
+            b = branch_index.map_reads_packed_device(pk, iv, d_o, lcap)
+            torch.cuda.synchronize()
+            _dense_equal(a, b, len(reads))
+    # the packed form itself, against a plain restatement: base j of chunk c in bits 2j, 2j+1 (A0 C1 T2 G3)
+    code = {65: 0, 67: 1, 84: 2, 71: 3}
+    host = bases
+    pkh, ivh = pk.cpu().numpy().view(np.uint32), iv.cpu().numpy().view(np.uint16)
+    for c in (0, 1, 7, len(host) // 16 - 1, len(host) // 16):
+        w = bad = 0
+        for j in range(16):
+            k = 16 * c + j
+            if k < len(host) and int(host[k]) in code:
+                w |= code[int(host[k])] << (2 * j)
+            else:
+                bad |= 1 << j
+        assert int(ivh[c]) == bad and (int(pkh[c]) & ~sum(3 << (2 * j) for j in range(16) if bad >> j & 1)) == w, c
+
+
+def test_packed_hand_over_synthetic_and_rate(gpu_device):
+    """2 M synthetic reads of 150 and 251 bases: packed and ASCII paths bit-identical; prints both rates."""
+    import torch
+    from genefuserust_amd import Indexer, synth
+    genes = synth.make_geneset("IDX-D", scale=0.25)
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    for L in (150, 251):
+        n = 2_000_000
+        rb = synth.make_reads(genes, n, read_len=L, mix="PANEL", seed=99 + L, device="cuda")
+        pk, iv = ix.pack_bases_device(rb.bases)
+        a = ix.map_reads_device(rb.bases, rb.offsets, L)
+        b = ix.map_reads_packed_device(pk, iv, rb.offsets, L)
+        torch.cuda.synchronize()
+        _dense_equal(a, b, n)
+        assert int((a[0] > 0).sum()) > 500
+    ix.close()

@@ -58,20 +58,26 @@ def main():
     from oracle import oracle_py
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
     from tests.test_pair_pipeline import _reference_policy
-    k = min(a.check, n)
     ox = oracle_py.OracleIndexer(genes.seqs)
-    o1, o2 = b1.offsets[:k + 1].cpu().numpy(), b2.offsets[:k + 1].cpu().numpy()
-    lb, lq = b1.bases[:o1[-1]].cpu().numpy().tobytes(), b1.quals[:o1[-1]].cpu().numpy().tobytes()
-    rb, rq = b2.bases[:o2[-1]].cpu().numpy().tobytes(), b2.quals[:o2[-1]].cpu().numpy().tobytes()
-    pairs = [(lb[o1[i]:o1[i + 1]], lq[o1[i]:o1[i + 1]], rb[o2[i]:o2[i + 1]], rq[o2[i]:o2[i + 1]]) for i in range(k)]
+    # sample: the first pairs of the pack and the pairs of the first hit records (so that matches are checked)
+    ids = sorted(set(range(min(a.check, n))) | {int(x) for x in rec["pair_id"][:300]})
+    o1, o2 = b1.offsets.cpu().numpy(), b2.offsets.cpu().numpy()
+    sel = torch.tensor(ids, device=dev)
+
+    def rows(t, off):
+        return [t[int(off[i]):int(off[i + 1])].cpu().numpy().tobytes() for i in ids]
+    L1b, L1q, L2b, L2q = rows(b1.bases, o1), rows(b1.quals, o1), rows(b2.bases, o2), rows(b2.quals, o2)
+    pairs = list(zip(L1b, L1q, L2b, L2q))
     want, _ = _reference_policy(oracle_py, ox, genes.reversed_flags, pairs)
-    flat = [(p, w) for p, ws in enumerate(want) for w in ws]
-    got = [h for h in rec if int(h["pair_id"]) < k]
+    flat = [(ids[p], w) for p, ws in enumerate(want) for w in ws]
+    idset = set(ids)
+    got = [h for h in rec if int(h["pair_id"]) in idset]
     bad = int(len(got) != len(flat))
     for h, (p, (source, on_rc, m_rev, seq, qual, rm)) in zip(got, flat):
         o, ln = int(h["seq_offset"]), int(h["read_len"])
         bad += not (int(h["pair_id"]) == p and int(h["source"]) == source and bool(h["flags"] & 1) == on_rc and
                     hb[o:o + ln] == seq and hq[o:o + ln] == qual)
+    k = len(ids)
     total = ms_cut1 + ms_cut2 + ms_scan
     text_bytes = int(t1.numel() + t2.numel())
     print(json.dumps({
