@@ -61,6 +61,9 @@ class GfIndexInfo(C.Structure):
 SEQMATCH_DTYPE = np.dtype([("seq_start", "<i4"), ("seq_end", "<i4"), ("position", "<i4"),
                            ("contig", "<i2"), ("pad", "<i2")])
 HIT_DTYPE = np.dtype([("read_id", "<i8"), ("n", "<i4"), ("pad", "<i4"), ("m", SEQMATCH_DTYPE, (2,))])
+READMATCH_DTYPE = np.dtype([("read_break", "<i4"), ("gap", "<i4"), ("left_distance", "<i4"), ("right_distance", "<i4"),
+                            ("left_position", "<i4"), ("right_position", "<i4"), ("left_contig", "<i2"),
+                            ("right_contig", "<i2")])
 PAIR_HIT_DTYPE = np.dtype([("pair_id", "<i8"), ("source", "<i4"), ("flags", "<i4"), ("read_len", "<i4"),
                            ("merge_diff", "<i4"), ("seq_offset", "<i8"), ("m", SEQMATCH_DTYPE, (2,))])
 assert SEQMATCH_DTYPE.itemsize == 16 and HIT_DTYPE.itemsize == 48 and PAIR_HIT_DTYPE.itemsize == 64
@@ -154,6 +157,8 @@ def lib() -> C.CDLL:
     L.gf_fast_merge.restype = C.c_int
     L.gf_index_set_gene_reversed.argtypes = [vp, vp, i32]
     L.gf_index_set_gene_reversed.restype = C.c_int
+    L.gf_pair_hits_finish.argtypes = [vp, vp, i64, vp, i64, vp, vp, i32]
+    L.gf_pair_hits_finish.restype = C.c_int
     L.gf_scan_pairs_retry_capacity.argtypes = [i64]
     L.gf_scan_pairs_retry_capacity.restype = i64
     L.gf_scan_pairs_device.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, i32, i64, i64, vp, i64, vp, vp, i64, vp, vp]

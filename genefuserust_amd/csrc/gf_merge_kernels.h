@@ -238,13 +238,18 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_MF_WAVES_PER_SIMD : 3) void gf_k
               anyA |= IA[j] & gf_len_mask2(len1, j);
               if (16 * j < len2) anyB |= gf_rc_flags(s_iv2, end2, j) & gf_len_mask2(len2, j);
             }
-            // a byte outside A/C/G/T in R1 and one outside ACGTacgt in R2 could be equal ('N' vs the
-            // 'N' of the reverse complement): only the byte loop knows
-            bytes_path = anyA && anyB;
-            if (!bytes_path) {
+            // A byte outside A/C/G/T in R1 and one outside ACGTacgt in R2 are EQUAL when R1's is a literal
+            // 'N' (the reverse complement of R2's is 'N', sequence.rs:51-59) and a mismatch otherwise.  The
+            // packed form only knows "unusable", so: the 16-column pre-test counts a column where R2 is
+            // unusable as no mismatch (it may only under-count: nothing is rejected wrongly), and the full
+            // count looks at R1's byte for the columns where both are unusable.  (The first form sent every
+            // such pair through the byte loop: with 0.1 % N in the genes nearly every wavefront had one.)
+            const bool both_bad = anyA && anyB;
+            {
               const int lim = len1 < len2 ? len1 : len2;
               const int o_hi = len1 - GF_MERGE_MIN_OVERLAP, o_lo = len1 - lim;  // offsets to try, high to low
               const uint32_t b0 = gf_rc_word(s_pk2, end2, 0), ib0 = gf_rc_flags(s_iv2, end2, 0);
+              const uint32_t pre_mask = 0x55555555u & ~ib0;
               bool done = false;
 #pragma unroll
               for (int j = PW - 1; j >= 0; --j) {
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_MF_WAVES_PER_SIMD : 3) void gf_k
                     const uint32_t w = __builtin_amdgcn_alignbit(ahi, alo, 2u * (uint32_t)s);
                     const uint32_t iw = __builtin_amdgcn_alignbit(ihi, ilo, 2u * (uint32_t)s);
                     const uint32_t x = w ^ b0;
-                    const uint32_t m = ((x | (x >> 1)) | iw | ib0) & 0x55555555u;
+                    const uint32_t m = ((x | (x >> 1)) | iw) & pre_mask;
                     if (__popc(m) > 2) continue;
                     // all columns of this overlap, 16 per word, R1's words cut from the tile
                     const int olen = len1 - o;
@@ -271,7 +276,16 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_MF_WAVES_PER_SIMD : 3) void gf_k
                         const uint32_t ww = __builtin_amdgcn_alignbit(s_pk1[(pa >> 4) + 1], s_pk1[pa >> 4], 2u * (pa & 15u));
                         const uint32_t fa = __builtin_amdgcn_alignbit(s_iv1[(pa >> 5) + 1], s_iv1[pa >> 5], pa & 31u) & 0xFFFFu;
                         const uint32_t xx = ww ^ gf_rc_word(s_pk2, end2, jj);
-                        uint32_t mm = ((xx | (xx >> 1)) | gf_spread16(fa) | gf_rc_flags(s_iv2, end2, jj)) & cm;
+                        const uint32_t fa2 = gf_spread16(fa), fb2 = gf_rc_flags(s_iv2, end2, jj);
+                        uint32_t mm = ((xx | (xx >> 1)) | fa2 | fb2) & cm;
+                        if (both_bad) {  // both unusable: equal iff R1's byte is a literal 'N'
+                          uint32_t bb = fa2 & fb2 & cm;
+                          while (bb) {
+                            const int bit = __builtin_ctz(bb);
+                            if (s1[o + 16 * jj + (bit >> 1)] == 'N') mm &= ~(1u << bit);
+                            bb &= bb - 1;
+                          }
+                        }
                         cnt += __popc(mm);
                         while (mm && c1 < 0) {
                           const int col = 16 * jj + (__builtin_ctz(mm) >> 1);

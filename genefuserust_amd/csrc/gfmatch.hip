@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,7 +14,9 @@
 #include <memory>
 #include <condition_variable>
 #include <mutex>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gfmatch.h"
@@ -292,6 +295,17 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   DeviceGuard guard(dev);
   if (!guard.ok) return fail(GF_ERR_NO_DEVICE, "hipSetDevice failed");
 
+  // GF_BUILD_TIMING=1: phase times of this call on stderr (experiments: multi-CSV mode rebuilds per CSV)
+  static const bool timing = getenv("GF_BUILD_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t_start = now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipDeviceSynchronize();
+    auto t = now();
+    fprintf(stderr, "[gf_index_build] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_start).count());
+    t_start = t;
+  };
   std::unique_ptr<gf_index> ix(new gf_index());
   ix->device = dev;
   if (const char* e = getenv("GF_MAP_VARIANT")) ix->map_variant = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;  // experiments
@@ -324,12 +338,14 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   }
   gene_off[(size_t)n_genes] = (uint32_t)total;
 
+  lap("host: slices, upper case");
   const uint32_t ntiles = (uint32_t)((total + GF_TILE_BASES - 1) / GF_TILE_BASES);
   const size_t cat_bytes = (size_t)ntiles * GF_TILE_BASES + 64;
   std::vector<uint8_t> cat(cat_bytes, 0);
   for (int32_t c = 0; c < n_genes; ++c)
     memcpy(cat.data() + gene_off[(size_t)c], ix->fusion_seq[(size_t)c].data(), ix->fusion_seq[(size_t)c].size());
 
+  lap("host: concatenation");
   // 8 slots per bucket, about 4 keys per bucket on average
   uint64_t nb64 = std::max<uint64_t>(16, (site_bound + 3) / 4);
   if (nb64 > 0x7FFFFFFFull) return fail(GF_ERR_CAPACITY, "table too large");
@@ -360,6 +376,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   GF_HIP(hipMemcpy(ix->d_lin_hi, lin_hi.data(), lin_hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   GF_HIP(hipMemcpy(ix->d_gene_len, glen.data(), glen.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 
+  lap("alloc, memset, copies in");
   GfGenes G;
   G.cat = d_cat.p;
   G.gene_off = d_goff.p;
@@ -396,6 +413,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
                        ix->d_gdu);
     GF_HIP(hipGetLastError());
   }
+  lap("table kernels");
   // presence filter over canonical 14-mers.  Indexes up to ~14 M keys: <= GF_BLOOM_KIB (default
   // 3 MiB) so that it lives in every XCD's L2, and seed+verify runs the filter pass for reads
   // without a candidate diagonal itself.  Up to ~30 M keys: 2.2 bits per key, up to
@@ -440,6 +458,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     }
   }
   GF_HIP(hipDeviceSynchronize());
+  lap("filter");
 
   ix->table.slots = ix->d_slots;
   ix->table.bloom = ix->d_bloom;
@@ -1143,16 +1162,9 @@ int64_t gf_edit_distance(const char* a, int64_t alen, const char* b, int64_t ble
   return (int64_t)host_edit_distance((const unsigned char*)a, (size_t)alen, (const unsigned char*)b, (size_t)blen);
 }
 
-int gf_fusion_map_read(const char* const* fusion_seqs, const int64_t* fusion_lens, int32_t n_genes,
-                       const uint8_t* gene_reversed, const char* seq, int64_t len, const gf_seqmatch* mapping,
-                       int32_t n_mapping, gf_readmatch* out) {
-  if (n_mapping < 0 || len < 0 || (n_mapping > 0 && !mapping)) return fail(GF_ERR_ARG, "bad argument");
-  if (n_mapping < 2) return GF_RM_NONE;  // fusion_mapper.rs:107-115
-  const int dir = gf_in_required_direction(mapping, n_mapping, gene_reversed, n_genes);
-  if (dir < 0) return dir;
-  if (!dir) return GF_RM_NONE_MAPABLE;   // :118-123
-  if (n_mapping != 2) return GF_RM_NONE_MAPABLE;  // make_match returns None (:155-157)
-  if (!out || !seq || !fusion_seqs || !fusion_lens) return fail(GF_ERR_ARG, "null argument");
+// make_match (fusion_mapper.rs:154-194) + calc_distance (:196-251) for a two-segment mapping
+static int gf_make_match_impl(const char* const* fusion_seqs, const int64_t* fusion_lens, int32_t n_genes, const char* seq,
+                              int64_t len, const gf_seqmatch* mapping, gf_readmatch* out) {
   gf_seqmatch left = mapping[0], right = mapping[1];
   if (left.seq_start > right.seq_start) std::swap(left, right);
   if (left.contig < 0 || left.contig >= n_genes || right.contig < 0 || right.contig >= n_genes)
@@ -1173,6 +1185,67 @@ int gf_fusion_map_read(const char* const* fusion_seqs, const int64_t* fusion_len
   out->right_distance = host_calc_ed(fusion_seqs[right.contig], fusion_lens[right.contig], seq + read_break + 1,
                                      right_len, right.position, right.position + right_len - 1);
   return GF_RM_MATCH;
+}
+
+int gf_fusion_map_read(const char* const* fusion_seqs, const int64_t* fusion_lens, int32_t n_genes,
+                       const uint8_t* gene_reversed, const char* seq, int64_t len, const gf_seqmatch* mapping,
+                       int32_t n_mapping, gf_readmatch* out) {
+  if (n_mapping < 0 || len < 0 || (n_mapping > 0 && !mapping)) return fail(GF_ERR_ARG, "bad argument");
+  if (n_mapping < 2) return GF_RM_NONE;  // fusion_mapper.rs:107-115
+  const int dir = gf_in_required_direction(mapping, n_mapping, gene_reversed, n_genes);
+  if (dir < 0) return dir;
+  if (!dir) return GF_RM_NONE_MAPABLE;   // :118-123
+  if (n_mapping != 2) return GF_RM_NONE_MAPABLE;  // make_match returns None (:155-157)
+  if (!out || !seq || !fusion_seqs || !fusion_lens) return fail(GF_ERR_ARG, "null argument");
+  return gf_make_match_impl(fusion_seqs, fusion_lens, n_genes, seq, len, mapping, out);
+}
+
+// The host-side tail for a whole list of pair hits: FusionMapper::make_match + calc_distance
+// (fusion_mapper.rs:154-251) per record, on n_threads host threads (records are independent).
+int gf_pair_hits_finish(const gf_index* idx, const gf_pair_hit* hits, int64_t n, const char* hit_bases,
+                        int64_t hit_bytes, gf_readmatch* out, int32_t* out_status, int32_t n_threads) {
+  if (!idx || n < 0 || hit_bytes < 0) return fail(GF_ERR_ARG, "null index or negative size");
+  if (n == 0) return GF_OK;
+  if (!hits || !out || !out_status || (hit_bytes > 0 && !hit_bases)) return fail(GF_ERR_ARG, "null argument");
+  const size_t ng = idx->fusion_seq.size();
+  std::vector<const char*> fp(ng);
+  std::vector<int64_t> fl(ng);
+  for (size_t c = 0; c < ng; ++c) {
+    fp[c] = idx->fusion_seq[c].data();
+    fl[c] = (int64_t)idx->fusion_seq[c].size();
+  }
+  for (int64_t k = 0; k < n; ++k)
+    if (hits[k].seq_offset < 0 || hits[k].read_len < 0 || hits[k].seq_offset + hits[k].read_len > hit_bytes)
+      return fail(GF_ERR_ARG, "a record's read lies outside hit_bases");
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads <= 0 ? 1 : n_threads, (n + 255) / 256));
+  std::atomic<int> err{GF_OK};
+  std::string err_msg;
+  std::mutex err_mu;
+  auto work = [&](int t) {
+    for (int64_t k = t; k < n; k += T) {
+      const gf_pair_hit& h = hits[k];
+      // make_match (fusion_mapper.rs:154-194) and calc_distance (:196-251); the gate of :118-123 has
+      // already passed on the device, so it is not asked again
+      gf_seqmatch m[2] = {h.m[0], h.m[1]};
+      int rc = gf_make_match_impl(fp.data(), fl.data(), (int32_t)ng, hit_bases + h.seq_offset, h.read_len, m, &out[k]);
+      out_status[k] = rc;
+      if (rc < 0) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        err = rc;
+        err_msg = g_err;
+        return;
+      }
+    }
+  };
+  if (T == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  if (err.load() != GF_OK) return fail(err.load(), err_msg);
+  return GF_OK;
 }
 
 int gf_index_fusion_map_read(const gf_index* idx, const uint8_t* gene_reversed, const char* seq, int64_t len,

@@ -148,25 +148,31 @@ def scan_pairs_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_qual
     return PairScan(hits, hb, hq, totals)
 
 
-def finish_pair_hits(mapper: FusionMapper, rec: np.ndarray, bases: bytes, quals: bytes) -> List[Tuple[int, ReadMatch]]:
+def finish_pair_hits(mapper: FusionMapper, rec: np.ndarray, bases: bytes, quals: bytes,
+                     threads: int = 8) -> List[Tuple[int, ReadMatch]]:
     """The host-side tail for the records of a pair scan: FusionMapper::make_match + calc_distance
-    (fusion_mapper.rs:154-251) on each matched read.  Returns (pair_id, ReadMatch) in push order."""
-    from .indexer import GenePos, SeqMatch
+    (fusion_mapper.rs:154-251) on each matched read — one gf_pair_hits_finish call for the whole
+    list (host threads inside the library).  Returns (pair_id, ReadMatch) in push order."""
+    from .indexer import GenePos
+    n = int(rec.shape[0])
+    if n == 0:
+        return []
+    rec = np.ascontiguousarray(rec)
+    rm = np.zeros(n, dtype=_lib.READMATCH_DTYPE)
+    status = np.zeros(n, dtype=np.int32)
+    _lib.check(_lib.lib().gf_pair_hits_finish(mapper.m_indexer._handle(), rec.ctypes.data, n, bases, len(bases),
+                                              rm.ctypes.data, status.ctypes.data, int(threads)))
     src_name = ("merged", "r1", "r2")
     out: List[Tuple[int, ReadMatch]] = []
-    for h in rec:
-        o, ln = int(h["seq_offset"]), int(h["read_len"])
-        seq = bases[o:o + ln]
-        mp = [SeqMatch(int(h["m"][k]["seq_start"]), int(h["m"][k]["seq_end"]),
-                       GenePos(int(h["m"][k]["contig"]), int(h["m"][k]["position"]))) for k in range(2)]
-        m, _ = mapper._tail(seq, mp)
-        if m is None:   # (make_match returns Some for every two-segment mapping in the required direction)
+    for h, r, st in zip(rec, rm, status):
+        if st != _lib.GF_RM_MATCH:
             continue
-        m.m_reversed = bool(h["flags"] & 2)
-        m.m_quality = quals[o:o + ln]
-        m.m_source = src_name[int(h["source"])]
-        if m.m_source == "merged":
-            m.m_merge_diff = int(h["merge_diff"])
+        o, ln = int(h["seq_offset"]), int(h["read_len"])
+        src = src_name[int(h["source"])]
+        m = ReadMatch(bases[o:o + ln], int(r["read_break"]), GenePos(int(r["left_contig"]), int(r["left_position"])),
+                      GenePos(int(r["right_contig"]), int(r["right_position"])), int(r["gap"]), int(r["left_distance"]),
+                      int(r["right_distance"]), bool(h["flags"] & 2), b"", src, quals[o:o + ln],
+                      int(h["merge_diff"]) if src == "merged" else -1)
         out.append((int(h["pair_id"]), m))
     return out
 

@@ -333,6 +333,12 @@ typedef struct gf_pair_hit {
 } gf_pair_hit;
 
 int gf_index_set_gene_reversed(gf_index* idx, const uint8_t* gene_reversed, int32_t n_genes);
+/* The host-side tail for the records of gf_scan_pairs_device (host copies of the records and of
+ * d_hit_bases): make_match + calc_distance (fusion_mapper.rs:154-251) per record on n_threads host
+ * threads — out[k] the ReadMatch fields, out_status[k] = GF_RM_MATCH.  (The direction gate of
+ * :118-123 has passed on the device.) */
+int gf_pair_hits_finish(const gf_index* idx, const gf_pair_hit* hits, int64_t n, const char* hit_bases,
+                        int64_t hit_bytes, gf_readmatch* out, int32_t* out_status, int32_t n_threads);
 int64_t gf_scan_pairs_retry_capacity(int64_t n);
 int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
                          int64_t l_bytes, const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets,
