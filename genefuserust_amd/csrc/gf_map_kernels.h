@@ -573,20 +573,41 @@ __device__ __forceinline__ void gf_finish_read(const GfTable& T, GfMapSmem<LCAP>
     const uint32_t g = sh + i;
     const uint32_t key = gf_window(S.codes[g >> 4], S.codes[(g >> 4) + 1], g);
     const uint32_t bad = gf_flags16(S.inv[g >> 5], S.inv[(g >> 5) + 1], g);
-    uint32_t val = 0;
-    if (act && !bad) val = gf_lookup(T, key);
-    uint32_t v[5];
-    const int nv = gf_sites(T, val, i, v);
+    // A window whose 16 bases equal the bases of the site on gp1 (or gp2) at this offset, that site
+    // being the only site of its key (gf_table.h: gdu), is known to return exactly that site from the
+    // table: its class is 3 (or 2) and the probe is skipped.  On a read that passed the gate nearly
+    // every window lies on one of the two diagonals; the others are probed as before.
     uint32_t cls = 0;
+    bool known = !(act && !bad);
+    if (!known) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      if (k < nv) {
-        const uint32_t x = v[k];
-        uint32_t f = 0;
-        if (x == t1a || x == t1b || x == t1c) f = 3;       // |gplong - gp1| <= 1
-        else if (x == t2a || x == t2b || x == t2c) f = 2;  // |gplong - gp2| <= 1
-        else if (x == lin0) f = 1;                         // gplong == 0
-        cls = f > cls ? f : cls;
+      for (int d = 0; d < 2; ++d) {
+        const uint32_t tb = d == 0 ? t1b : t2b;
+        const uint32_t a = tb + i;
+        if (!known && tb != GF_NONE_LIN && (a >> 4) + 2 < T.gd_words) {
+          const uint32_t gk = gf_window(T.gdu[2 * (a >> 4)], T.gdu[2 * (a >> 4) + 2], a);
+          const uint32_t ubit = (T.gdu[2 * (a >> 4) + 1] >> (2u * (a & 15u))) & 1u;
+          if (ubit && gk == key) {
+            cls = d == 0 ? 3u : 2u;
+            known = true;
+          }
+        }
+      }
+    }
+    if (!known) {
+      const uint32_t val = gf_lookup(T, key);
+      uint32_t v[5];
+      const int nv = gf_sites(T, val, i, v);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        if (k < nv) {
+          const uint32_t x = v[k];
+          uint32_t f = 0;
+          if (x == t1a || x == t1b || x == t1c) f = 3;       // |gplong - gp1| <= 1
+          else if (x == t2a || x == t2b || x == t2c) f = 2;  // |gplong - gp2| <= 1
+          else if (x == lin0) f = 1;                         // gplong == 0
+          cls = f > cls ? f : cls;
+        }
       }
     }
     if (act) S.u.p2.wcls[w] = (uint8_t)cls;

@@ -823,7 +823,11 @@ __global__ __launch_bounds__(WAVES * 64, LCAP <= 256 ? 8 : (LCAP <= 1024 ? 3 : 1
     if constexpr (PACKED) sh = gf_stage_read_packed<LCAP>(S, g_pk, g_iv, off0, L, lane);
     else sh = gf_stage_read<LCAP>(S, bases + off0, L, lane);
     gf_wave_lds_sync();
-    const int nvotes = gf_first_pass_probe_all<LCAP>(T, S, L, sh, lane);
+    // reads of up to 256 bases: seeds + verification against the genes, probes only for the windows
+    // neither explains (the vote list is the same as probing every window; gf_map_kernels.h, producer B)
+    int nvotes;
+    if constexpr (LCAP <= 256) nvotes = gf_first_pass_seed_verify<LCAP>(T, S, L, sh, lane);
+    else nvotes = gf_first_pass_probe_all<LCAP>(T, S, L, sh, lane);
     gf_finish_read<LCAP>(T, S, L, sh, nvotes, lane, r, counts, matches);
   }
 }

@@ -70,6 +70,7 @@ struct GfTable {
   // same layout, bit 2(p%16): the site with code p exists and is the only site of its
   // key.  Interleaved so that one cache line serves both.
   const uint32_t* gdu;
+  uint32_t gd_words;        // word pairs in gdu: positions 0 .. 16 * gd_words - 1 are addressable
   // presence filter over 14-mers (one 32-bit word, two bits per element), consulted
   // before any bucket probe of a window that is expected to miss.  For every key of the
   // table its last 14 bases (key >> 4) and its first 14 bases (key & 0x0FFFFFFF) are

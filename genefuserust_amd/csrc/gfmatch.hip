@@ -469,6 +469,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   ix->table.lin_hi = ix->d_lin_hi;
   ix->table.gene_len = ix->d_gene_len;
   ix->table.gdu = ix->d_gdu;
+  ix->table.gd_words = (uint32_t)gd_words;
   ix->table.nbuckets = nbuckets;
   ix->table.n_genes = n_genes;
 
