@@ -490,7 +490,7 @@ def bench_multi_csv(args, cfg, world, rank, local_rank, dev, barrier, seed, gene
     jobs = plan_multi_csv(n_csv, n, rank, world)
     sets = {j.csv: synth.make_geneset(shapes[j.csv], scale=args.scale, seed=1000 + 37 * j.csv, **gene_kw) for j in jobs}
     # the resident reads: drawn from CSV 0's and CSV 1's genes (every rank holds the same set)
-    base_sets = [synth.make_geneset(shapes[k], scale=args.scale, seed=1000 + 37 * k, **gene_kw) for k in (0, 1)]
+    base_sets = [synth.make_geneset(("IDX-C", "IDX-D")[k], scale=args.scale, seed=1000 + 37 * k, **gene_kw) for k in (0, 1)]
     half = n // 2
     ra = synth.make_reads(base_sets[0], half, read_len=L, mix=args.mix, seed=seed, device=str(dev))
     rb = synth.make_reads(base_sets[1], n - half, read_len=L, mix=args.mix, seed=seed + 1, device=str(dev))

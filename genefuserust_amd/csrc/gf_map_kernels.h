@@ -588,7 +588,9 @@ __device__ __forceinline__ void gf_finish_read(const GfTable& T, GfMapSmem<LCAP>
           const uint32_t gk = gf_window(T.gdu[2 * (a >> 4)], T.gdu[2 * (a >> 4) + 2], a);
           const uint32_t ubit = (T.gdu[2 * (a >> 4) + 1] >> (2u * (a & 15u))) & 1u;
           if (ubit && gk == key) {
-            cls = d == 0 ? 3u : 2u;
+            // the class of that one site's diagonal, by the reference's order of tests (gp2 within one
+            // of gp1 — e.g. (c,-1) and (c+1,0), whose i64 keys are neighbours — is class 3, not 2)
+            cls = (tb == t1a || tb == t1b || tb == t1c) ? 3u : ((tb == t2a || tb == t2b || tb == t2c) ? 2u : (tb == lin0 ? 1u : 0u));
             known = true;
           }
         }
