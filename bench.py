@@ -80,7 +80,16 @@ def traffic_entry(shape: str, n: int, L: int):
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         tj = json.load(open(tpath))
-        return tj.get("%s_%d_%d" % (shape, n, L))
+        e = tj.get("%s_%d_%d" % (shape, n, L))
+        if e is None:   # the same workload measured at another batch size: per-read traffic is the same
+            for k, v in tj.items():
+                m = k.split("_")
+                if len(m) == 3 and m[0] == shape and m[2] == str(L) and m[1].isdigit():
+                    e = dict(v)
+                    e["hbm_bytes_per_launch"] = int(v["hbm_bytes_per_launch"] * (n / int(m[1])))
+                    e["source"] = "%s (measured at %s reads per launch, scaled by the read count)" % (v.get("source"), m[1])
+                    break
+        return e
     except Exception:
         return None
 
