@@ -54,6 +54,18 @@ def main():
     t0 = time.perf_counter()
     done = finish_pair_hits(fm, rec, hb, hq)
     tail_s = time.perf_counter() - t0
+    # the library call alone (make_match + calc_distance per record on 8 host threads), without the Python objects
+    from genefuserust_amd import _lib
+    rm = np.zeros(rec.shape[0], dtype=_lib.READMATCH_DTYPE)
+    st = np.zeros(rec.shape[0], dtype=np.int32)
+    recc = np.ascontiguousarray(rec)
+    c_s = {}
+    for threads in (1, 8):
+        t0 = time.perf_counter()
+        for _ in range(5):
+            _lib.check(_lib.lib().gf_pair_hits_finish(ix._handle(), recc.ctypes.data, rec.shape[0], hb, len(hb), rm.ctypes.data,
+                                                      st.ctypes.data, threads))
+        c_s[threads] = (time.perf_counter() - t0) / 5
     # parity sample: the records of the first pairs against the oracle-driven policy
     from oracle import oracle_py
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -87,7 +99,9 @@ def main():
         "scan_pairs_only_pairs_per_s": n / (ms_scan / 1e3),
         "totals": tot, "junction_pairs": int((kinds == 2).sum()),
         "host_tail": {"hits": len(done), "seconds": round(tail_s, 4), "hits_per_s": len(done) / tail_s if tail_s else None,
-                      "note": "make_match + calc_distance per hit through the C ABI from Python, one thread"},
+                      "note": "finish_pair_hits: gf_pair_hits_finish + one Python ReadMatch object per hit",
+                      "library_call_seconds": {str(k): round(v, 5) for k, v in c_s.items()},
+                      "library_hits_per_s_8_threads": rec.shape[0] / c_s[8] if c_s[8] else None},
         "text_bytes": text_bytes, "text_GBps": text_bytes / (total / 1e3) / 1e9,
         "parity": {"checked_pairs": k, "records_expected": len(flat), "mismatches": bad}}))
     return 1 if bad else 0
