@@ -227,3 +227,96 @@ def test_scan_pair_end_report(gpu_device, tmp_path):
     assert se[0].m_left_gp == top.m_left_gp and se[0].m_right_gp == top.m_right_gp
     assert 2 <= len(se[0].m_matches) <= len(top.m_matches) and all(len(m.m_read) == 150 for m in se[0].m_matches)
     assert all(m.m_name.endswith(b"/1") and len(m.m_quality) == 150 for m in se[0].m_matches)
+
+
+@pytest.mark.gpu
+def test_files_to_fusion_list_equals_the_independent_model_chain(gpu_device, tmp_path):
+    """The whole scan on the device and the host mirrors (files -> records -> gf_scan_pairs_device ->
+    tail -> filters -> sort -> clusters -> qualified fusions) against a chain that shares NO code with
+    it: oracle/indexer_model.py from the FASTA / CSV / FASTQ bytes to the fusion list (dict index,
+    scratch k-mers, textbook Levenshtein, plain slicing).  Three genes (one reversed), two planted
+    fusions read off both strands, a deletion-like pair inside one gene, background pairs, reads with N
+    and with low-quality mismatches in the overlap."""
+    from genefuserust_amd.scan import scan_pair_end_report
+    rng = np.random.default_rng(77)
+    chrs = {"chr1": rand_seq(rng, 9000), "chr2": rand_seq(rng, 8000), "chr3": rand_seq(rng, 7000)}
+    fa_bytes = b"".join(b">" + k.encode() + b" some description\n" + v + b"\n" for k, v in chrs.items())
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(fa_bytes)
+    csv = tmp_path / "f.csv"
+    csv.write_text(CSV)
+    genes = model.csv_genes(CSV)
+    seqs = [chrs[g[1]][g[2]:g[3]] for g in genes]   # gene slices as make_index cuts them
+    ga, gb, gr = seqs
+    junctions = [ga[2300 - 300:2300] + gb[3100:3100 + 300],          # GA -> GB
+                 ga[1200 - 300:1200] + rc(gr)[len(gr) - 900:len(gr) - 900 + 300],   # GA -> GR read off GR's other strand
+                 gb[800 - 300:800] + gb[4000:4000 + 300]]            # inside GB, far apart
+    l_txt, r_txt = [], []
+    for k in range(90):
+        if k % 3 != 2:
+            j = junctions[k % 3 if k % 9 < 6 else 2]
+            lo = int(rng.integers(90, 230))
+            f = j[lo:lo + int(rng.integers(190, 290))]
+            if k % 2:
+                f = rc(f)
+        else:
+            f = rand_seq(rng, 280)
+        s1, s2 = bytearray(f[:150]), bytearray(rc(f)[:150])
+        q1, q2 = bytearray(b"F" * len(s1)), bytearray(b"F" * len(s2))
+        if k % 7 == 0:   # a sequencing error with a low quality: still merges, corrected from the mate
+            p = int(rng.integers(5, len(s1) - 5))
+            s1[p] = b"ACGT"[(b"ACGT".index(s1[p]) + 1) % 4]
+            q1[p] = ord("#")
+        if k % 13 == 0:
+            s2[int(rng.integers(0, len(s2)))] = ord("N")
+        l_txt += [b"@pair%03d/1" % k, bytes(s1), b"+", bytes(q1)]
+        r_txt += [b"@pair%03d/2" % k, bytes(s2), b"+", bytes(q2)]
+    r1, r2 = tmp_path / "R1.fq", tmp_path / "R2.fq"
+    r1.write_bytes(b"\n".join(l_txt) + b"\n")
+    r2.write_bytes(b"\n".join(r_txt))   # no final newline, like the reference's own test files
+    results, counters = scan_pair_end_report(str(fa), str(csv), str(r1), str(r2))
+
+    # ---- the independent chain ----
+    contigs = model.fasta_contigs(fa_bytes)
+    mslices = [contigs[g[1]][g[2]:g[3]].decode() for g in genes]
+    im = model.IndexModel(mslices)
+    rev = [g[5] for g in genes]
+
+    def m_map(read: str):
+        return model.fusion_map_read(im.fusion_seq, rev, read, im.map_read(read))
+
+    found = []   # (read_break, len, name, dict)
+    recs1, recs2 = model.fastq_records(r1.read_bytes()), model.fastq_records(r2.read_bytes())
+    assert len(recs1) == len(recs2) == 90
+    for (n1, s1, _, q1), (n2, s2, _, q2) in zip(recs1, recs2):
+        s1, q1, s2, q2 = s1.decode(), q1.decode(), s2.decode(), q2.decode()
+        mg = model.fast_merge(s1, q1, s2, q2)
+        cands = [(mg[0], n1 + b" merged_diff_%d" % mg[2], False)] if mg else [(s1, n1, True), (s2, n2, True)]
+        for seq, name, flag in cands:
+            st, rm = m_map(seq)
+            if st == 1:
+                seq = model.revcomp(seq)
+                st, rm = m_map(seq)
+            if st == 2:
+                found.append((rm["read_break"], len(seq), name, dict(
+                    seq=seq, brk=rm["read_break"], left=(rm["left_contig"], rm["left_position"]),
+                    right=(rm["right_contig"], rm["right_position"]), gap=rm["gap"], ld=rm["left_distance"],
+                    rd=rm["right_distance"])))
+    kept = [f for f in found if model.match_filter(f[3]["seq"], f[3]["brk"], f[3]["left"], f[3]["right"], f[3]["ld"],
+                                                   f[3]["rd"]) == 0]
+    assert counters["matches_before_filtering"] == len(found) >= 30
+    assert len(found) - len(kept) == counters["complexity"] + counters["distance"] + counters["indels"]
+    by = {}
+    for f in kept:
+        by.setdefault(len(genes) * f[3]["right"][0] + f[3]["left"][0], []).append(f)
+    groups = [[f[3] for f in model.match_sort(by[k])] for k in sorted(by)]
+    for st in (Settings(), Settings(output_deletions=True, output_untranslated=True)):
+        if st.output_deletions:
+            results, _ = scan_pair_end_report(str(fa), str(csv), str(r1), str(r2), settings=st)
+        want = model.cluster_model(groups, genes, im.fusion_seq, st.unique_requirement, st.output_deletions,
+                                   st.output_untranslated)
+        assert len(results) == len(want) >= (2 if not st.output_deletions else 3)
+        for fr, mo in zip(results, want):
+            same(fr, mo)
+    assert any("GA" in fr.m_title and "GB" in fr.m_title for fr in results)
+    assert any("GR" in fr.m_title for fr in results)

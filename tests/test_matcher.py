@@ -92,3 +92,47 @@ def test_small_reference_panics_like_the_reference():
         Matcher(contigs, [b"ACGT"])  # a candidate shorter than 15 bases: the range underflows
     # a read whose windows all start with A or C finds both keys in the index: no panic, no match
     assert Matcher(contigs, [b"ACACACACACACACACACACAAAA"]).do_match(b"ACACACACACACACACACACAAAA") is None
+
+
+@pytest.mark.parametrize("seed,n_contigs,length,gaps,polya", [(1, 2, 600, 0, 0), (2, 3, 2000, 3, 2), (3, 2, 4000, 30, 30),
+                                                                (5, 4, 3000, 80, 0), (7, 2, 40, 0, 0)])
+def test_cpp_matcher_mirror(tmp_path, seed, n_contigs, length, gaps, polya):
+    """include/gf_matcher.hpp (the C++ form of the same as-is behaviour) builds the same index and gives
+    the same outcome per read as the Python mirror, which the literal model checks above."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_matcher")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "test_matcher.cpp"), "-o", exe], check=True)
+    rng = np.random.default_rng(seed)
+    if length < 100:   # a small reference: keys with few sites vote, reads panic
+        contigs = {"a": b"ACGTTGCAAGGCTTAACCGGTTAACC", "b": b"CGTTGCAAGGCTTAACCGGTTAACCA"}
+        reads = [b"ACGTTGCAAGGCTTAACCGGTTAACCGGATCGATCG", b"ACACACACACACACACACACAAAA", rand_seq(rng, 60)]
+    else:
+        contigs = genome(rng, n_contigs, length, gaps, polya)
+        reads = [rand_seq(rng, int(rng.integers(15, 160))) for _ in range(12)]
+        reads += [b"ACGTNNACGT" * 6, b"A" * 40, b"acgtacgtacgtacgtacgt", b"CCCCCCCCCCCCCCCCCCCCGGGGGG"]
+    case = tmp_path / "case.txt"
+    with open(case, "w") as f:
+        f.write("%d %d\n" % (len(contigs), len(reads)))
+        for k, v in contigs.items():
+            f.write("%s %s\n" % (k, v.decode()))
+        for r in reads:
+            f.write(r.decode() + "\n")
+    out = subprocess.run([exe, str(case)], capture_output=True, text=True, check=True).stdout.split("\n")
+    m = Matcher(contigs, reads)
+    assert out[0] == "bloom %d" % m.bloom_bits
+    assert out[1].split()[1:] == m.m_contig_names
+    keys = sorted(m.m_kmer_positions)
+    for j, k in enumerate(keys):
+        want = "key %d %d" % (k, len(m.m_kmer_positions[k])) + "".join(" %d:%d" % s for s in m.m_kmer_positions[k])
+        assert out[2 + j] == want, k
+    got = out[2 + len(keys):2 + len(keys) + len(reads)]
+    assert got == [("panic" if outcome(m, r) == "panic" else "none") for r in reads]
+    try:
+        kept, _ = remove_alignables([ReadMatch(r, 70, GenePos(0, 100), GenePos(1, 200), 0, 0, 0) for r in reads], contigs)
+        want_kept = "kept %d" % len(kept)
+    except MatcherPanic:
+        want_kept = "kept panic"
+    assert out[2 + len(keys) + len(reads)] == want_kept
