@@ -21,7 +21,7 @@
 #include "../../include/gfmatch.h"
 #include "gf_compact_kernels.h"
 
-#define GF_PTILE 1024  // pairs per tile
+#define GF_PTILE 256  // pairs per tile: one per thread, so that a wavefront reads and writes consecutive pairs
 #define GF_PPER (GF_PTILE / GF_CTHREADS)
 
 #define GF_PS_NONE 0u

@@ -331,21 +331,46 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     if (len > GF_KMER) site_bound += 2ull * (uint64_t)(len - GF_KMER);
     if (lin_cursor > (uint64_t)GF_LIN_MASK || total > 0xFFFFFFFFull - 2 * GF_TILE_BASES)
       return fail(GF_ERR_CAPACITY, "gene set too large: total span exceeds the 29-bit site-code space");
-    std::string& s = ix->fusion_seq[(size_t)c];
-    s.assign(len > 0 ? gene_seqs[c] : "", (size_t)len);
-    for (auto& ch : s)
-      if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 'a' + 'A');
   }
   gene_off[(size_t)n_genes] = (uint32_t)total;
 
-  lap("host: slices, upper case");
+  // upper-cased slices (Indexer.m_fusion_seq) and their concatenation for the device, gene by gene on a few
+  // host threads: in multi-CSV mode this runs once per CSV, 15 MB for a cancer-sized gene set
   const uint32_t ntiles = (uint32_t)((total + GF_TILE_BASES - 1) / GF_TILE_BASES);
   const size_t cat_bytes = (size_t)ntiles * GF_TILE_BASES + 64;
-  std::vector<uint8_t> cat(cat_bytes, 0);
-  for (int32_t c = 0; c < n_genes; ++c)
-    memcpy(cat.data() + gene_off[(size_t)c], ix->fusion_seq[(size_t)c].data(), ix->fusion_seq[(size_t)c].size());
+  std::unique_ptr<uint8_t[]> cat_mem(new uint8_t[cat_bytes]);  // (not zero-filled: every byte is written below)
+  struct { uint8_t* p; uint8_t* data() const { return p; } } cat{cat_mem.get()};
+  {
+    auto prep = [&](int32_t c) {
+      const size_t len = glen[(size_t)c];
+      std::string& s = ix->fusion_seq[(size_t)c];
+      s.resize(len);
+      const unsigned char* src = (const unsigned char*)gene_seqs[c];
+      unsigned char* d1 = (unsigned char*)&s[0];
+      unsigned char* d2 = cat.data() + gene_off[(size_t)c];
+      for (size_t k = 0; k < len; ++k) {
+        const unsigned char ch = src[k];
+        const unsigned char up = (unsigned char)(ch - ((unsigned char)(ch - 'a') < 26u ? 32 : 0));  // indexer.rs:159
+        d1[k] = up;
+        d2[k] = up;
+      }
+    };
+    const int T = (int)std::min<uint64_t>(8, std::max<uint64_t>(1, total >> 20));  // a thread per MB, at most 8
+    if (T <= 1) {
+      for (int32_t c = 0; c < n_genes; ++c) prep(c);
+    } else {
+      std::atomic<int32_t> next{0};
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t)
+        th.emplace_back([&] {
+          for (int32_t c = next.fetch_add(1); c < n_genes; c = next.fetch_add(1)) prep(c);
+        });
+      for (auto& x : th) x.join();
+    }
+    memset(cat.data() + total, 0, cat_bytes - total);
+  }
 
-  lap("host: concatenation");
+  lap("host: slices, upper case, concatenation");
   // 8 slots per bucket, about 4 keys per bucket on average
   uint64_t nb64 = std::max<uint64_t>(16, (site_bound + 3) / 4);
   if (nb64 > 0x7FFFFFFFull) return fail(GF_ERR_CAPACITY, "table too large");

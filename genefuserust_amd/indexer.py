@@ -250,7 +250,7 @@ class Indexer:
         # Indexer::with_loaded_ref (indexer.rs:100-112)
         self.m_reference = reference
         self.m_fusions = list(fusions)
-        self.m_fusion_seq: List[str] = []
+        self._fusion_seq: Optional[List[str]] = []
         self._device = device
         self._h: Optional[C.c_void_p] = None
         self._gene_slices: Optional[List[Optional[bytes]]] = None
@@ -289,12 +289,21 @@ class Indexer:
         # Fusion::is_reversed() per gene, for the direction rule of the device-resident pair pipeline
         rev = np.array([f.is_reversed() for f in self.m_fusions] or [0], dtype=np.uint8)
         _lib.check(L.gf_index_set_gene_reversed(h, rev.ctypes.data, n))
-        self.m_fusion_seq = []
-        for c in range(n):
-            ln = L.gf_index_fusion_seq(h, c, None, 0)
-            buf = C.create_string_buffer(max(int(ln), 1))
-            L.gf_index_fusion_seq(h, c, buf, ln)
-            self.m_fusion_seq.append(buf.raw[:ln].decode("latin-1"))
+        self._fusion_seq = None   # fetched from the library on first use (multi-CSV mode never asks)
+
+    @property
+    def m_fusion_seq(self) -> List[str]:
+        """Indexer.m_fusion_seq (indexer.rs:77, :170): the upper-cased gene slices, "" for an unresolved gene."""
+        if self._fusion_seq is None:
+            L, h = _lib.lib(), self._handle()
+            out = []
+            for c in range(len(self._gene_slices or [])):
+                ln = L.gf_index_fusion_seq(h, c, None, 0)
+                buf = C.create_string_buffer(max(int(ln), 1))
+                L.gf_index_fusion_seq(h, c, buf, ln)
+                out.append(buf.raw[:ln].decode("latin-1"))
+            self._fusion_seq = out
+        return self._fusion_seq
 
     def _handle(self) -> C.c_void_p:
         if self._h is None:
