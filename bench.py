@@ -48,6 +48,11 @@ READS_TEXT = ("reads are independent draws (40 % background / 59.9 % single-gene
               "them reverse-complemented — mate-like orientation, not N(300,30) fragment pairs: the metric is per read")
 
 
+def _lib_compact_ws_bytes(n: int) -> int:
+    from genefuserust_amd import _lib
+    return _lib.lib().gf_compact_workspace_bytes(n)
+
+
 def algo_bytes_per_read(L: int) -> int:
     p1 = (L - 16) // 2 + 1 if L >= 16 else 0
     return L + 8 + 8 * p1 + 4
@@ -201,6 +206,12 @@ def main() -> None:
             exch = HitExchange(cap=max(4096, n // 512), device=dev)
             exchange_name = "HitExchange (one asynchronous fixed-capacity all-gather, pipelined one step deep)"
     pending = []
+    # the step's outputs are preallocated (two sets, alternating: the exchange of step k may still read set k
+    # while step k+1 writes the other): nothing is allocated inside the timed region
+    cws = int(_lib_compact_ws_bytes(n))
+    out_sets = [(torch.empty((max(n // 16, 1), 6), dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev),
+                 torch.empty(cws, dtype=torch.uint8, device=dev)) for _ in range(2)]
+    step_no = [0]
 
     def step(ev=None):
         if ev is not None:
@@ -208,7 +219,9 @@ def main() -> None:
         ix.map_reads_device(reads.bases, reads.offsets, L, counts, matches)
         if ev is not None:
             ev[1].record(stream)
-        hits, n_hits = ix.compact_hits_device(counts, matches, n, read_id_base=read_id_base, cap=n // 16)
+        step_no[0] += 1
+        hits, n_hits = ix.compact_hits_device(counts, matches, n, read_id_base=read_id_base, cap=n // 16,
+                                              out=out_sets[step_no[0] & 1])
         if world > 1:
             if exch is None:
                 return allgather_hits(hits, n_hits)
@@ -241,12 +254,17 @@ def main() -> None:
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     out = None
+    dbg = os.environ.get("GF_BENCH_DEBUG") == "1"
     for k in range(args.steps):
         out = step(evs[k])
+        if dbg:
+            print("step %d queued at %.3f ms" % (k, 1e3 * (time.perf_counter() - t0)), file=sys.stderr, flush=True)
     last = drain()
     out = last if last is not None else out
     barrier()
     elapsed = time.perf_counter() - t0
+    if dbg:
+        print("all steps done at %.3f ms" % (1e3 * elapsed), file=sys.stderr, flush=True)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

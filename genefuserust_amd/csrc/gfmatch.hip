@@ -372,7 +372,9 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
 
   lap("host: slices, upper case, concatenation");
   // 8 slots per bucket, about 4 keys per bucket on average
-  uint64_t nb64 = std::max<uint64_t>(16, (site_bound + 3) / 4);
+  uint64_t sites_per_bucket = 4;
+  if (const char* e = getenv("GF_SITES_PER_BUCKET")) sites_per_bucket = (uint64_t)std::max(1, std::min(7, atoi(e)));  // experiments
+  uint64_t nb64 = std::max<uint64_t>(16, (site_bound + sites_per_bucket - 1) / sites_per_bucket);
   if (nb64 > 0x7FFFFFFFull) return fail(GF_ERR_CAPACITY, "table too large");
   const uint32_t nbuckets = (uint32_t)nb64;
   const uint64_t nslots = (uint64_t)nbuckets * GF_SLOTS_PER_BUCKET;

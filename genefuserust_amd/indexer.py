@@ -410,18 +410,27 @@ class Indexer:
         return counts, matches
 
     def compact_hits_device(self, counts, matches, n: int, read_id_base: int = 0, cap: Optional[int] = None,
-                            stream=None):
-        """Ordered compaction on the device; returns (hits int64[cap, 6] view of gf_hit, n_hits tensor)."""
+                            stream=None, out=None):
+        """Ordered compaction on the device; returns (hits int64[cap, 6] view of gf_hit, n_hits tensor).
+        ``out`` = (hits, n_hits, workspace) tensors of an earlier call to write into (a steady-state loop
+        allocates nothing)."""
         import torch
         dev = counts.device
         cap = n if cap is None else cap
-        hits = torch.empty((max(cap, 1), 6), dtype=torch.int64, device=dev)
-        n_hits = torch.zeros(1, dtype=torch.int64, device=dev)
-        ws = torch.empty(int(_lib.lib().gf_compact_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        if out is None:
+            hits = torch.empty((max(cap, 1), 6), dtype=torch.int64, device=dev)
+            n_hits = torch.zeros(1, dtype=torch.int64, device=dev)
+            ws = torch.empty(int(_lib.lib().gf_compact_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        else:
+            hits, n_hits, ws = out
+            cap = min(cap, hits.shape[0])
+            assert ws.numel() >= int(_lib.lib().gf_compact_workspace_bytes(n))
         st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         _lib.check(_lib.lib().gf_compact_hits_device(self._handle(), counts.data_ptr(), matches.data_ptr(), n,
                                                      read_id_base, hits.data_ptr(), cap, n_hits.data_ptr(),
                                                      ws.data_ptr(), st))
+        if out is None:
+            self._last_compact_ws = ws   # (kept alive until the next call: the kernels may still be reading it)
         return hits, n_hits
 
     # -- in_required_direction (indexer.rs:541-608) ---------------------------
