@@ -186,3 +186,53 @@ def test_scan_pairs_full_size_properties(gpu_device, oracle):
         assert ox.map_read(hb[o:o + ln]) == got
         assert oracle.in_required_direction(got, genes.reversed_flags)
     ix.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk_bytes,final_newline", [(40_000, True), (7_000, False), (1_000_000, True)])
+def test_text_stream_equals_the_one_shot_scan(gpu_device, chunk_bytes, final_newline):
+    """FASTQ text handed over in raw chunks (boundaries anywhere: mid-line, mid-record, the two files out
+    of step because R2's names are longer) gives the records of the one-shot scan of the whole files;
+    R2 has three records more than R1 (the shorter file ends both)."""
+    from genefuserust_amd import Indexer
+    from genefuserust_amd.fastq import fastq_cut_device
+    from genefuserust_amd.read_pair import scan_pairs_device
+    from genefuserust_amd.scan_stream import scan_pair_text_stream
+    import torch
+    g = json.load(open(GOLDEN))
+    genes = [None if x is None else x.encode() for x in g["genes"]]
+    ix = Indexer.from_gene_slices(genes, g["reversed"])
+    ix.make_index()
+    rng = np.random.default_rng(3)
+    pairs = _make_pairs(rng, genes, 700)
+    t1 = b"\n".join(b"@p%d/1\n%s\n+\n%s" % (k, p[0], p[1]) for k, p in enumerate(pairs))
+    extra = pairs + pairs[:3]
+    t2 = b"\n".join(b"@pair_with_a_longer_name_%d/2\n%s\n+\n%s" % (k, p[2], p[3]) for k, p in enumerate(extra))
+    if final_newline:
+        t1, t2 = t1 + b"\n", t2 + b"\n"
+    a1, a2 = np.frombuffer(t1, dtype=np.uint8).copy(), np.frombuffer(t2, dtype=np.uint8).copy()
+    got = list(scan_pair_text_stream(ix, a1, a2, chunk_bytes=chunk_bytes, max_read_len=150))
+    assert sum(t[3]["pairs"] for t in got) == 700
+    assert len(got) >= (2 if chunk_bytes < 200_000 else 1)
+    # the one-shot scan of the same records
+    b1 = fastq_cut_device(ix, torch.from_numpy(a1).cuda())
+    b2 = fastq_cut_device(ix, torch.from_numpy(a2).cuda())
+    o2 = b2.offsets[:701]
+    want = scan_pairs_device(ix, b1.bases, b1.quals, b1.offsets, b2.bases[:int(o2[-1])], b2.quals[:int(o2[-1])], o2, 150,
+                             hits_cap=2100, bytes_cap=700_000).download()
+    rec = np.concatenate([t[0] for t in got])
+    assert rec.shape[0] == want[0].shape[0] > 100
+    for f in ("pair_id", "source", "flags", "read_len", "merge_diff"):
+        assert (rec[f] == want[0][f]).all(), f
+    assert rec["m"].tobytes() == want[0]["m"].tobytes()
+    # the reads travel with their records (offsets are per chunk)
+    k = 0
+    for r, hb, hq, tot in got:
+        for h in r:
+            o, ln = int(h["seq_offset"]), int(h["read_len"])
+            w = want[0][k]
+            wo = int(w["seq_offset"])
+            assert hb[o:o + ln] == want[1][wo:wo + ln] and hq[o:o + ln] == want[2][wo:wo + ln]
+            k += 1
+    assert sum(t[3]["merged_pairs"] for t in got) == want[3]["merged_pairs"]
+    ix.close()
