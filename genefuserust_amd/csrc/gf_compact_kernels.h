@@ -127,14 +127,3 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_compact_write(
     ++pos;
   }
 }
-
-
-// Small results back to the host WITHOUT a DMA copy: a kernel stores them into pinned (device-visible)
-// host memory.  A cudaMemcpy-style read-back shares the copy engines with whatever upload is in flight
-// and waits behind it (measured: every 8-byte read-back of a streamed FASTQ scan took the 9 ms of the
-// next chunk's upload); stores from a kernel go over the link at once.  16-byte vectors, both pointers
-// 16-byte aligned, n16 = number of vectors.
-__global__ void gf_k_copy_to_host(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x)
-    dst[i] = src[i];
-}

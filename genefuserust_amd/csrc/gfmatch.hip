@@ -165,16 +165,8 @@ static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** 
       W.base = nullptr;
       W.bytes = 0;
     }
-    // a quarter more than asked for: packs of slightly different sizes (a streamed FASTQ) must not
-    // free and allocate gigabytes every time one is a little larger than the last
-    const size_t want = need + need / 4;
-    if (hipMalloc(&W.base, want) == hipSuccess) {
-      W.bytes = want;
-    } else {
-      (void)hipGetLastError();
-      GF_HIP(hipMalloc(&W.base, need));
-      W.bytes = need;
-    }
+    GF_HIP(hipMalloc(&W.base, need));
+    W.bytes = need;
   }
   *out = W.base;
   return GF_OK;
@@ -884,14 +876,8 @@ static int lane_reserve(HostLane& L, size_t need) {
     L.arena = nullptr;
     L.arena_bytes = 0;
   }
-  const size_t want = need + need / 4;  // (slack: see acquire_workspace)
-  if (hipMalloc(&L.arena, want) == hipSuccess) {
-    L.arena_bytes = want;
-  } else {
-    (void)hipGetLastError();
-    GF_HIP(hipMalloc(&L.arena, need));
-    L.arena_bytes = need;
-  }
+  GF_HIP(hipMalloc(&L.arena, need));
+  L.arena_bytes = need;
   return GF_OK;
 }
 
@@ -1659,21 +1645,6 @@ struct gf_stream {
   std::vector<Slot> slots;
   int head = 0, tail = 0, live = 0;
 };
-
-int gf_copy_to_host_device(const gf_index* idx, const void* d_src, void* h_pinned_dst, int64_t nbytes, void* stream) {
-  if (!idx || nbytes < 0) return fail(GF_ERR_ARG, "null index or negative size");
-  if (nbytes == 0) return GF_OK;
-  if (!d_src || !h_pinned_dst) return fail(GF_ERR_ARG, "null pointer");
-  if (((uintptr_t)d_src | (uintptr_t)h_pinned_dst) & 15u) return fail(GF_ERR_ARG, "pointers must be 16-byte aligned");
-  DeviceGuard guard(idx->device);
-  void* dptr = nullptr;
-  GF_HIP(hipHostGetDevicePointer(&dptr, h_pinned_dst, 0));  // (fails for memory that is not pinned)
-  const int64_t n16 = (nbytes + 15) / 16;  // the last vector may run up to 15 bytes past nbytes: both buffers must hold it
-  const int grid = (int)std::min<int64_t>((n16 + 255) / 256, (int64_t)idx->n_cus * 4);
-  hipLaunchKernelGGL(gf_k_copy_to_host, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_src, (uint4*)dptr, n16);
-  GF_HIP(hipGetLastError());
-  return GF_OK;
-}
 
 void* gf_host_alloc(int64_t bytes) {
   if (bytes <= 0) return nullptr;

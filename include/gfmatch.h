@@ -367,13 +367,6 @@ void gf_stream_close(gf_stream* s);
 /* pinned host memory for the buffers handed to gf_stream_submit / gf_map_reads* (hipHostMalloc) */
 void* gf_host_alloc(int64_t bytes);
 void gf_host_free(void* p);
-/* Small results back to pinned host memory by a kernel's stores instead of a DMA copy (a read-back by
- * hipMemcpy queues behind whatever upload is in flight on the copy engines): copies nbytes, rounded up to
- * whole 16-byte vectors, from device memory to h_pinned_dst (gf_host_alloc / hipHostMalloc memory; both
- * pointers 16-byte aligned, both buffers at least the rounded size), ordered on `stream`; the host reads
- * after synchronising that stream.  The device entry points that return counts (d_n_lines, d_n_bad,
- * d_totals, d_n_hits) accept pinned host pointers directly for the same reason. */
-int gf_copy_to_host_device(const gf_index* idx, const void* d_src, void* h_pinned_dst, int64_t nbytes, void* stream);
 
 /* --- instrumentation -------------------------------------------------------
  * With profiling on, gf_map_reads_device brackets its mapping kernel with HIP
