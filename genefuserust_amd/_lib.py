@@ -175,6 +175,8 @@ def lib() -> C.CDLL:
     L.gf_stream_collect.restype = C.c_int
     L.gf_stream_close.argtypes = [vp]
     L.gf_stream_close.restype = None
+    L.gf_copy_from_host_device.argtypes = [vp, vp, vp, i64, vp]
+    L.gf_copy_from_host_device.restype = C.c_int
     L.gf_host_alloc.argtypes = [i64]
     L.gf_host_alloc.restype = vp
     L.gf_host_free.argtypes = [vp]

@@ -165,8 +165,16 @@ static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** 
       W.base = nullptr;
       W.bytes = 0;
     }
-    GF_HIP(hipMalloc(&W.base, need));
-    W.bytes = need;
+    // a quarter more than asked for: packs of slightly different sizes (a streamed FASTQ) must not
+    // free and allocate gigabytes every time one is a little larger than the last
+    const size_t want = need + need / 4;
+    if (hipMalloc(&W.base, want) == hipSuccess) {
+      W.bytes = want;
+    } else {
+      (void)hipGetLastError();
+      GF_HIP(hipMalloc(&W.base, need));
+      W.bytes = need;
+    }
   }
   *out = W.base;
   return GF_OK;
@@ -876,8 +884,14 @@ static int lane_reserve(HostLane& L, size_t need) {
     L.arena = nullptr;
     L.arena_bytes = 0;
   }
-  GF_HIP(hipMalloc(&L.arena, need));
-  L.arena_bytes = need;
+  const size_t want = need + need / 4;  // (slack: see acquire_workspace)
+  if (hipMalloc(&L.arena, want) == hipSuccess) {
+    L.arena_bytes = want;
+  } else {
+    (void)hipGetLastError();
+    GF_HIP(hipMalloc(&L.arena, need));
+    L.arena_bytes = need;
+  }
   return GF_OK;
 }
 
@@ -1645,6 +1659,15 @@ struct gf_stream {
   std::vector<Slot> slots;
   int head = 0, tail = 0, live = 0;
 };
+
+int gf_copy_from_host_device(const gf_index* idx, const void* h_src, void* d_dst, int64_t nbytes, void* stream) {
+  if (!idx || nbytes < 0) return fail(GF_ERR_ARG, "null index or negative size");
+  if (nbytes == 0) return GF_OK;
+  if (!h_src || !d_dst) return fail(GF_ERR_ARG, "null pointer");
+  DeviceGuard guard(idx->device);
+  GF_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)nbytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return GF_OK;
+}
 
 void* gf_host_alloc(int64_t bytes) {
   if (bytes <= 0) return nullptr;

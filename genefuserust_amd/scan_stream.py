@@ -29,8 +29,9 @@ CARRY_MAX = 1 << 20  # bytes kept in front of a chunk for the previous chunk's t
 class _Side:
     """One FASTQ text: a host byte source and two device buffers the chunks alternate between."""
 
-    def __init__(self, text: np.ndarray, chunk_bytes: int, dev):
+    def __init__(self, text: np.ndarray, chunk_bytes: int, dev, handle):
         import torch
+        self.h = handle
         assert text.dtype == np.uint8 and text.ndim == 1
         self.text = text
         self.pos = 0
@@ -47,9 +48,11 @@ class _Side:
         n = int(max(0, min(nbytes, self.text.size - self.pos)))
         self.chunk_len[slot] = n
         if n:
-            src = torch.from_numpy(self.text[self.pos:self.pos + n])
-            with torch.cuda.stream(stream):
-                self.bufs[slot][CARRY_MAX:CARRY_MAX + n].copy_(src, non_blocking=True)
+            # through the library's own hipMemcpyAsync: torch only treats memory of its own pinned allocator as
+            # pinned, and copies from anything else (gf_host_alloc memory included) synchronously
+            src = self.text[self.pos:self.pos + n]
+            _lib.check(_lib.lib().gf_copy_from_host_device(self.h, src.ctypes.data, self.bufs[slot].data_ptr() + CARRY_MAX, n,
+                                                           stream.cuda_stream))
         self.pos += n
 
 
@@ -64,7 +67,7 @@ def scan_pair_text_stream(indexer: Indexer, r1_text: np.ndarray, r2_text: np.nda
     dev = torch.device("cuda", indexer.info()["device"])
     copy_stream = torch.cuda.Stream(dev)
     main = torch.cuda.current_stream(dev)
-    sides = [_Side(r1_text, chunk_bytes, dev), _Side(r2_text, chunk_bytes, dev)]
+    sides = [_Side(r1_text, chunk_bytes, dev, indexer._handle()), _Side(r2_text, chunk_bytes, dev, indexer._handle())]
     L, h = _lib.lib(), indexer._handle()
     ready = [None, None]   # per slot: event after which the slot's copies have landed
     free = [None, None]    # per slot: event after which the slot's buffers may be overwritten

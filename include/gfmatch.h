@@ -367,6 +367,9 @@ void gf_stream_close(gf_stream* s);
 /* pinned host memory for the buffers handed to gf_stream_submit / gf_map_reads* (hipHostMalloc) */
 void* gf_host_alloc(int64_t bytes);
 void gf_host_free(void* p);
+/* hipMemcpyAsync host -> device on `stream`, for hosts that hold no HIP binding of their own (a
+ * streamed FASTQ: genefuserust_amd/scan_stream.py).  Asynchronous when h_src is pinned. */
+int gf_copy_from_host_device(const gf_index* idx, const void* h_src, void* d_dst, int64_t nbytes, void* stream);
 
 /* --- instrumentation -------------------------------------------------------
  * With profiling on, gf_map_reads_device brackets its mapping kernel with HIP
