@@ -170,13 +170,18 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_classify(GfPairIn P, in
     tile_rc[blockIdx.x] = (uint32_t)ta;
     tile_rb[blockIdx.x] = (uint32_t)tb;
   }
-  // merged pairs, for the totals
-  const uint64_t any = __ballot(merged != 0);
-  if (any) {
+  // merged pairs, for the totals: one atomic per block (a same-address atomic per wavefront was most of
+  // this kernel's time: 156 K of them per 10 M pairs)
+  {
     int msum = merged;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) msum += __shfl_down(msum, o);
-    if ((threadIdx.x & 63) == 0 && msum) atomicAdd(n_merged, (unsigned long long)msum);
+    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = msum;   // (s_a is free again: gf_block_scan2 ends with a barrier)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int bsum = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+      if (bsum) atomicAdd(n_merged, (unsigned long long)bsum);
+    }
   }
 }
 
