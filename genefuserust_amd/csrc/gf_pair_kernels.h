@@ -144,7 +144,7 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_len_offsets(const int32_t* _
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_classify(GfPairIn P, int64_t n, uint8_t* __restrict__ st,
                                                                   uint32_t* __restrict__ tile_rc,
                                                                   uint32_t* __restrict__ tile_rb,
-                                                                  unsigned long long* __restrict__ n_merged) {
+                                                                  uint32_t* __restrict__ tile_mc) {
   __shared__ int s_a[4];
   __shared__ long long s_b[4];
   const int64_t p0 = (int64_t)blockIdx.x * GF_PTILE + (int64_t)threadIdx.x * GF_PPER;
@@ -170,18 +170,14 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_classify(GfPairIn P, in
     tile_rc[blockIdx.x] = (uint32_t)ta;
     tile_rb[blockIdx.x] = (uint32_t)tb;
   }
-  // merged pairs, for the totals: one atomic per block (a same-address atomic per wavefront was most of
-  // this kernel's time: 156 K of them per 10 M pairs)
+  // merged pairs of the tile, for the totals (summed by a scan of the tile array: no atomics)
   {
     int msum = merged;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) msum += __shfl_down(msum, o);
     if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = msum;   // (s_a is free again: gf_block_scan2 ends with a barrier)
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const int bsum = s_a[0] + s_a[1] + s_a[2] + s_a[3];
-      if (bsum) atomicAdd(n_merged, (unsigned long long)bsum);
-    }
+    if (threadIdx.x == 0) tile_mc[blockIdx.x] = (uint32_t)(s_a[0] + s_a[1] + s_a[2] + s_a[3]);
   }
 }
 
@@ -388,10 +384,10 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_final_write(
 }
 
 __global__ void gf_k_pair_totals(const int64_t* __restrict__ d_hits, const int64_t* __restrict__ d_hit_bytes,
-                                 const unsigned long long* __restrict__ n_merged, int64_t hits_cap, int64_t bytes_cap,
+                                 const int64_t* __restrict__ n_merged, int64_t hits_cap, int64_t bytes_cap,
                                  int64_t* __restrict__ totals) {
   totals[0] = *d_hits;
   totals[1] = *d_hit_bytes;
-  totals[2] = (int64_t)*n_merged;
+  totals[2] = *n_merged;
   if (*d_hits > hits_cap || *d_hit_bytes > bytes_cap) totals[4] |= 2;
 }

@@ -1558,8 +1558,8 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   const size_t o_cM = cv.take((size_t)n), o_c1 = cv.take((size_t)n), o_c2 = cv.take((size_t)n);
   const size_t o_mM = cv.take((size_t)n * 32), o_m1 = cv.take((size_t)n * 32), o_m2 = cv.take((size_t)n * 32);
   const size_t o_st = cv.take((size_t)n * 3), o_slot = cv.take((size_t)n * 3 * 4);
-  const size_t o_tc = cv.take((size_t)std::max(ntiles, nctiles) * 4 * 2);      // two uint32 per tile
-  const size_t o_to = cv.take((size_t)std::max(ntiles, nctiles) * 8 * 2);      // two int64 per tile
+  const size_t o_tc = cv.take((size_t)std::max(ntiles, nctiles) * 4 * 3);      // three uint32 per tile
+  const size_t o_to = cv.take((size_t)std::max(ntiles, nctiles) * 8 * 3);      // three int64 per tile
   const size_t o_scal = cv.take(256);                                          // scalars: totals of the scans, merged pairs
   const size_t o_roff = cv.take(((size_t)retry_cap + 1) * 8);
   const size_t o_rb = cv.take((size_t)retry_bytes_cap + 64), o_rq = cv.take((size_t)retry_bytes_cap + 64);
@@ -1576,8 +1576,8 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   gf_seqmatch *mM = (gf_seqmatch*)(wp + o_mM), *m1 = (gf_seqmatch*)(wp + o_m1), *m2 = (gf_seqmatch*)(wp + o_m2);
   uint8_t* stt = wp + o_st; int32_t* slot_of = (int32_t*)(wp + o_slot);
   const int64_t tmax = std::max(ntiles, nctiles);
-  uint32_t *tcA = (uint32_t*)(wp + o_tc), *tcB = tcA + tmax;
-  int64_t *toA = (int64_t*)(wp + o_to), *toB = toA + tmax;
+  uint32_t *tcA = (uint32_t*)(wp + o_tc), *tcB = tcA + tmax, *tcC = tcB + tmax;
+  int64_t *toA = (int64_t*)(wp + o_to), *toB = toA + tmax, *toC = toB + tmax;
   int64_t* scal = (int64_t*)(wp + o_scal);  // [0] merged bytes, [1] retries, [2] retry bytes, [3] hits, [4] hit bytes, [5] merged pairs
   int64_t* r_off = (int64_t*)(wp + o_roff); uint8_t* rb = wp + o_rb; uint8_t* rq = wp + o_rq;
   uint8_t* cR = wp + o_cR; gf_seqmatch* mR = (gf_seqmatch*)(wp + o_mR);
@@ -1610,8 +1610,8 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   P.m_bases = mb; P.m_quals = mq; P.m_off = m_off; P.m_len = m_len; P.m_diff = m_diff;
   P.cM = cM; P.c1 = c1; P.c2 = c2; P.mM = mM; P.m1 = m1; P.m2 = m2;
   P.gene_reversed = idx->d_gene_rev; P.n_genes = idx->table.n_genes;
-  hipLaunchKernelGGL(gf_k_pair_classify, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, stt, tcA, tcB,
-                     (unsigned long long*)(scal + 5));
+  hipLaunchKernelGGL(gf_k_pair_classify, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, stt, tcA, tcB, tcC);
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcC, ntiles, toC, scal + 5);
   hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcA, ntiles, toA, scal + 1);
   hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcB, ntiles, toB, scal + 2);
   hipLaunchKernelGGL(gf_k_pair_retry_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, (const uint8_t*)stt,
@@ -1631,7 +1631,7 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
                      (const int64_t*)r_off, (const uint8_t*)rb, (const uint8_t*)rq, (const int64_t*)toA, (const int64_t*)toB,
                      (gf_pair_hit*)d_hits, hits_cap, (uint8_t*)d_hit_bases, (uint8_t*)d_hit_quals, hit_bytes_cap);
   hipLaunchKernelGGL(gf_k_pair_totals, dim3(1), dim3(1), 0, st, (const int64_t*)(scal + 3), (const int64_t*)(scal + 4),
-                     (const unsigned long long*)(scal + 5), hits_cap, hit_bytes_cap, totals);
+                     (const int64_t*)(scal + 5), hits_cap, hit_bytes_cap, totals);
   GF_HIP(hipGetLastError());
   return GF_OK;
 }

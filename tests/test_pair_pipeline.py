@@ -236,3 +236,25 @@ def test_text_stream_equals_the_one_shot_scan(gpu_device, chunk_bytes, final_new
             k += 1
     assert sum(t[3]["merged_pairs"] for t in got) == want[3]["merged_pairs"]
     ix.close()
+
+
+@pytest.mark.gpu
+def test_pack_sizes_beyond_the_32_bit_candidate_space_are_rejected(gpu_device):
+    """gf_scan_pairs_device numbers its 3 n candidates in 32 bits: a larger pack is an error, not a wrap-around
+    (the mapping entry splits large batches into spans instead: test_span_split_of_large_batches)."""
+    import torch
+    from genefuserust_amd import Indexer, _lib
+    ix = Indexer.from_gene_slices([b"ACGT" * 100])
+    ix.make_index()
+    d = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    o = torch.zeros(8, dtype=torch.int64, device="cuda")
+    tot = torch.zeros(8, dtype=torch.int64, device="cuda")
+    rc = _lib.lib().gf_scan_pairs_device(ix._handle(), d.data_ptr(), d.data_ptr(), o.data_ptr(), 0, d.data_ptr(), d.data_ptr(),
+                                         o.data_ptr(), 0, (1 << 31) // 3 + 1, 150, 0, 0, d.data_ptr(), 0, d.data_ptr(),
+                                         d.data_ptr(), 0, tot.data_ptr(), 0)
+    assert rc == _lib.GF_ERR_CAPACITY
+    rc = _lib.lib().gf_scan_pairs_device(ix._handle(), d.data_ptr(), d.data_ptr(), o.data_ptr(), 0, d.data_ptr(), d.data_ptr(),
+                                         o.data_ptr(), 0, 4, 3000, 0, 0, d.data_ptr(), 0, d.data_ptr(), d.data_ptr(), 0,
+                                         tot.data_ptr(), 0)
+    assert rc == _lib.GF_ERR_READ_TOO_LONG   # a merged read of 2 x 3000 bases would exceed GF_MAX_READ_LEN
+    ix.close()
