@@ -255,42 +255,64 @@ __global__ void gf_k_classify_count(const uint64_t* slots, uint64_t nslots,
   }
 }
 
-__global__ void gf_k_classify_assign(uint64_t* slots, uint64_t nslots, unsigned long long* stats) {
+// A thread takes one bucket (8 consecutive slots = one 64-byte line), a block 256 buckets per round: the room
+// in dupes[] for the round's 2..5-fold keys is ONE atomic on the shared counter (a block scan hands out the
+// parts).  The first form took one per wavefront: a quarter of a million same-address atomics on a
+// cancer-sized table, most of the kernel's 1.16 ms.
+__global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uint64_t nslots, unsigned long long* stats) {
+  __shared__ uint32_t s_wave[4];
+  __shared__ unsigned long long s_base;
+  const uint64_t nbuckets = nslots / GF_SLOTS_PER_BUCKET;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t rounds = (nslots + stride - 1) / stride;  // whole waves stay in the loop for the shuffles
+  const uint64_t rounds = (nbuckets + stride - 1) / stride;  // whole blocks stay in the loop for the barriers
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint64_t it = 0; it < rounds; ++it) {
-    const uint64_t s = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t val = 0, c = 0;
-    uint32_t* valp = nullptr;
-    if (s < nslots) {
-      valp = (uint32_t*)(slots + s);
-      val = *valp;
-      c = val & GF_VAL_LOW;
+    const uint64_t b = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t val[GF_SLOTS_PER_BUCKET], want[GF_SLOTS_PER_BUCKET];
+    uint32_t mine = 0;
+    uint64_t* base_slot = slots + b * GF_SLOTS_PER_BUCKET;
+#pragma unroll
+    for (int k = 0; k < GF_SLOTS_PER_BUCKET; ++k) {
+      val[k] = b < nbuckets ? (uint32_t)base_slot[k] : 0u;
+      const uint32_t c = val[k] & GF_VAL_LOW;
+      want[k] = (c >= 2 && c <= GF_DUP_THRESHOLD) ? c : 0u;
+      mine += want[k];
     }
-    // room in dupes[] for the 2..5-fold keys of this wave: one atomic per wave, not per key
-    const uint32_t want = (c >= 2 && c <= GF_DUP_THRESHOLD) ? c : 0u;
-    uint32_t incl = want;
+    uint32_t incl = mine;
+#pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t y = __shfl_up(incl, o);
-      if ((int)(threadIdx.x & 63) >= o) incl += y;
+      if (lane >= o) incl += y;
     }
-    const uint32_t total = __shfl(incl, 63);
-    unsigned long long base = 0;
-    if (total) {
-      if ((threadIdx.x & 63) == 0) base = atomicAdd(stats + 6, (unsigned long long)total);
-      base = __shfl(base, 0);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) before += s_wave[w];
+      total += s_wave[w];
     }
-    if (!c) continue;
-    uint32_t nv;
-    if (c == 1) {
-      nv = GF_TYPE_UNIQUE << GF_TYPE_SHIFT;
-    } else if (c <= GF_DUP_THRESHOLD) {
-      const uint32_t start = (uint32_t)base + incl - want;
-      nv = (GF_TYPE_DUPES << GF_TYPE_SHIFT) | (c << GF_DUPE_COUNT_SHIFT) | start;
-    } else {
-      nv = GF_TYPE_HIGH << GF_TYPE_SHIFT;
+    if (threadIdx.x == 0 && total) s_base = atomicAdd(stats + 6, (unsigned long long)total);
+    __syncthreads();
+    uint32_t start = (uint32_t)(total ? s_base : 0ull) + before + incl - mine;
+    if (b < nbuckets) {
+#pragma unroll
+      for (int k = 0; k < GF_SLOTS_PER_BUCKET; ++k) {
+        const uint32_t c = val[k] & GF_VAL_LOW;
+        if (!c) continue;
+        uint32_t nv;
+        if (c == 1) {
+          nv = GF_TYPE_UNIQUE << GF_TYPE_SHIFT;
+        } else if (c <= GF_DUP_THRESHOLD) {
+          nv = (GF_TYPE_DUPES << GF_TYPE_SHIFT) | (c << GF_DUPE_COUNT_SHIFT) | start;
+          start += c;
+        } else {
+          nv = GF_TYPE_HIGH << GF_TYPE_SHIFT;
+        }
+        *(uint32_t*)(base_slot + k) = (val[k] & GF_VAL_OVF) | nv;
+      }
     }
-    *valp = (val & GF_VAL_OVF) | nv;
+    __syncthreads();  // s_wave / s_base are rewritten in the next round
   }
 }
 
