@@ -258,3 +258,53 @@ def test_pack_sizes_beyond_the_32_bit_candidate_space_are_rejected(gpu_device):
                                          tot.data_ptr(), 0)
     assert rc == _lib.GF_ERR_READ_TOO_LONG   # a merged read of 2 x 3000 bases would exceed GF_MAX_READ_LEN
     ix.close()
+
+
+@pytest.mark.gpu
+def test_scan_pairs_with_250_base_reads(gpu_device, oracle):
+    """2 x 250-base pairs: merged reads of up to 470 bases leave the flat kernels' 320-base limit and take the
+    1024-base wave-per-read class; R1 / R2 take the 16-word flat kernels.  Against the oracle-driven policy."""
+    import torch
+    from genefuserust_amd import FusionMapper, Indexer
+    from genefuserust_amd.read_pair import finish_pair_hits, pack_reads, scan_pairs_device
+    g = json.load(open(GOLDEN))
+    genes = [None if x is None else x.encode() for x in g["genes"]]
+    ix = Indexer.from_gene_slices(genes, g["reversed"])
+    ix.make_index()
+    ox = oracle.OracleIndexer(genes)
+    rng = np.random.default_rng(12)
+    g0, g1 = genes[0], genes[1]
+    pairs = []
+    for k in range(400):
+        if k % 4 != 3:
+            p, q = int(rng.integers(400, len(g0) - 400)), int(rng.integers(400, len(g1) - 500))
+            frag = g0[p - 300:p] + g1[q:q + 300]
+        else:
+            frag = rand_seq(rng, 600)
+        lo = int(rng.integers(0, 100))
+        flen = int(rng.integers(260, 500))
+        f = frag[lo:lo + flen]
+        if k % 2:
+            f = rc(f)
+        rl = min(250, len(f))
+        pairs.append((f[:rl], b"F" * rl, rc(f)[:rl], b"F" * rl))
+    want, n_merged = _reference_policy(oracle, ox, g["reversed"], pairs)
+    lb, lo_ = pack_reads([p[0] for p in pairs]); lq, _ = pack_reads([p[1] for p in pairs])
+    rb, ro = pack_reads([p[2] for p in pairs]); rq, _ = pack_reads([p[3] for p in pairs])
+    t = [torch.from_numpy(a).cuda() for a in (lb, lq, lo_, rb, rq, ro)]
+    rec, hb, hq, tot = scan_pairs_device(ix, *t, 250, hits_cap=1200, bytes_cap=1200 * 500).download()
+    assert tot["overflow"] == 0 and tot["merged_pairs"] == n_merged > 100
+    flat = [(p, w) for p, ws in enumerate(want) for w in ws]
+    assert tot["hits"] == len(flat) == rec.shape[0] > 100
+    long_merged = 0
+    for h, (p, (source, on_rc, m_rev, seq, qual, rm)) in zip(rec, flat):
+        assert int(h["pair_id"]) == p and int(h["source"]) == source and bool(h["flags"] & 1) == on_rc
+        o, ln = int(h["seq_offset"]), int(h["read_len"])
+        assert hb[o:o + ln] == seq and hq[o:o + ln] == qual
+        long_merged += source == 0 and ln > 320
+    assert long_merged > 20
+    done = finish_pair_hits(FusionMapper(ix), rec, hb, hq)
+    for (pid, m), (p, (source, on_rc, m_rev, seq, qual, rm)) in zip(done, flat):
+        assert (m.m_read_break, m.m_gap, m.m_left_distance, m.m_right_distance) == (
+            rm["read_break"], rm["gap"], rm["left_distance"], rm["right_distance"])
+    ix.close()
