@@ -35,6 +35,7 @@ struct GfPairIn {
   const int64_t* m_off;              // int64[n+1]: an empty slot for a pair that did not merge
   const int32_t* m_len;              // 0 = not merged
   const int32_t* m_diff;
+  const int32_t* m_rank;             // merged pair p is read m_rank[p] of the (compact) merged mapping pass
   const uint8_t *cM, *c1, *c2;       // counts of the three mapping passes
   const gf_seqmatch *mM, *m1, *m2;
   const uint8_t* gene_reversed;      // Fusion::is_reversed() per gene; null = all false
@@ -63,7 +64,8 @@ __device__ __forceinline__ void gf_pair_candidate(const GfPairIn& P, int64_t p, 
                                                   const gf_seqmatch*& m) {
   if (s == 0) {
     const int64_t o = P.m_off[p];
-    bases = P.m_bases + o; quals = P.m_quals + o; len = P.m_len[p]; cnt = P.cM[p]; m = P.mM + 2 * p;
+    const int64_t j = P.m_len[p] > 0 ? (int64_t)P.m_rank[p] : 0;   // (cM / mM are indexed by merged read, not by pair)
+    bases = P.m_bases + o; quals = P.m_quals + o; len = P.m_len[p]; cnt = P.m_len[p] > 0 ? P.cM[j] : (uint8_t)0; m = P.mM + 2 * j;
   } else if (s == 1) {
     const int64_t o = P.l_off[p];
     bases = P.l_bases + o; quals = P.l_quals + o; len = (int32_t)(P.l_off[p + 1] - o); cnt = P.c1[p]; m = P.m1 + 2 * p;
@@ -106,55 +108,81 @@ __device__ __forceinline__ void gf_block_scan2(int a, long long b, int* s_a, lon
   __syncthreads();
 }
 
-// exclusive prefix sum of int32 lengths into int64 offsets[n+1] (the merged reads' slots): tile sums ...
+// The merged reads' slots: exclusive prefix sums of the int32 lengths (bytes: m_off, int64[n+1]) and of the
+// merged flags (reads: m_rank), tile sums first ...
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_len_tile_sums(const int32_t* __restrict__ len, int64_t n,
-                                                                  uint32_t* __restrict__ tile_sums) {
-  __shared__ int s_wave[4];
+                                                                  uint32_t* __restrict__ tile_bytes,
+                                                                  uint32_t* __restrict__ tile_reads) {
+  __shared__ int s_a[4];
+  __shared__ long long s_b[4];
   const int64_t r0 = (int64_t)blockIdx.x * GF_CTILE + (int64_t)threadIdx.x * GF_CPER;
   int c = 0;
+  long long b = 0;
   for (int k = 0; k < GF_CPER; ++k)
-    if (r0 + k < n) c += len[r0 + k] > 0 ? len[r0 + k] : 0;
-  int total;
-  gf_block_exclusive_scan(c, s_wave, &total);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = (uint32_t)total;
+    if (r0 + k < n && len[r0 + k] > 0) { c += 1; b += len[r0 + k]; }
+  int ea, ta; long long eb, tb;
+  gf_block_scan2(c, b, s_a, s_b, ea, eb, ta, tb);
+  if (threadIdx.x == 0) {
+    tile_reads[blockIdx.x] = (uint32_t)ta;
+    tile_bytes[blockIdx.x] = (uint32_t)tb;
+  }
 }
-// ... and the offsets (after gf_k_compact_scan of the tile sums)
+// ... then (after gf_k_compact_scan of both tile arrays) the offsets: m_off[p] for every pair (an empty slot for
+// a pair that did not merge), m_rank[p] and the compact c_off[m_rank[p]] = m_off[p] for the pairs that did.
+// The merged mapping pass runs over c_off: the real reads first, empty reads behind them (gf_k_len_tail) —
+// whole tiles of empty reads cost next to nothing, 84 % empty slots among the real ones cost a full pass.
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_len_offsets(const int32_t* __restrict__ len, int64_t n,
-                                                                const int64_t* __restrict__ tile_offsets,
-                                                                const int64_t* __restrict__ d_total,
-                                                                int64_t* __restrict__ offsets) {
-  __shared__ int s_wave[4];
+                                                                const int64_t* __restrict__ tile_off_bytes,
+                                                                const int64_t* __restrict__ tile_off_reads,
+                                                                const int64_t* __restrict__ d_total_bytes,
+                                                                int64_t* __restrict__ offsets, int32_t* __restrict__ rank,
+                                                                int64_t* __restrict__ c_off) {
+  __shared__ int s_a[4];
+  __shared__ long long s_b[4];
   const int64_t r0 = (int64_t)blockIdx.x * GF_CTILE + (int64_t)threadIdx.x * GF_CPER;
   int c = 0;
+  long long b = 0;
   for (int k = 0; k < GF_CPER; ++k)
-    if (r0 + k < n) c += len[r0 + k] > 0 ? len[r0 + k] : 0;
-  int total;
-  int64_t pos = tile_offsets[blockIdx.x] + gf_block_exclusive_scan(c, s_wave, &total);
+    if (r0 + k < n && len[r0 + k] > 0) { c += 1; b += len[r0 + k]; }
+  int ea, ta; long long eb, tb;
+  gf_block_scan2(c, b, s_a, s_b, ea, eb, ta, tb);
+  int64_t pos = tile_off_bytes[blockIdx.x] + eb;
+  int64_t j = tile_off_reads[blockIdx.x] + ea;
   for (int k = 0; k < GF_CPER; ++k) {
     const int64_t r = r0 + k;
     if (r >= n) break;
     offsets[r] = pos;
-    pos += len[r] > 0 ? len[r] : 0;
+    if (len[r] > 0) {
+      rank[r] = (int32_t)j;
+      c_off[j] = pos;
+      pos += len[r];
+      j += 1;
+    }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = *d_total;
+  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = *d_total_bytes;
+}
+// the empty reads behind the merged ones: c_off[k] = total bytes for k = number of merged pairs .. n
+__global__ void gf_k_len_tail(const int64_t* __restrict__ d_n_merged, const int64_t* __restrict__ d_total_bytes, int64_t n,
+                              int64_t* __restrict__ c_off) {
+  const int64_t nm = *d_n_merged, tot = *d_total_bytes;
+  for (int64_t k = nm + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= n; k += (int64_t)gridDim.x * blockDim.x)
+    c_off[k] = tot;
 }
 
 // ---- classify: which candidates matched as they are, which are searched again reversed ----
 // tile_rc / tile_rb: retries (reads / bytes) per tile.
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_classify(GfPairIn P, int64_t n, uint8_t* __restrict__ st,
                                                                   uint32_t* __restrict__ tile_rc,
-                                                                  uint32_t* __restrict__ tile_rb,
-                                                                  uint32_t* __restrict__ tile_mc) {
+                                                                  uint32_t* __restrict__ tile_rb) {
   __shared__ int s_a[4];
   __shared__ long long s_b[4];
   const int64_t p0 = (int64_t)blockIdx.x * GF_PTILE + (int64_t)threadIdx.x * GF_PPER;
-  int rc = 0, merged = 0;
+  int rc = 0;
   long long rb = 0;
   for (int k = 0; k < GF_PPER; ++k) {
     const int64_t p = p0 + k;
     if (p >= n) break;
     const bool is_merged = P.m_len[p] > 0;
-    merged += is_merged;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       uint32_t v = GF_PS_NONE;
@@ -169,15 +197,6 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_classify(GfPairIn P, in
   if (threadIdx.x == 0) {
     tile_rc[blockIdx.x] = (uint32_t)ta;
     tile_rb[blockIdx.x] = (uint32_t)tb;
-  }
-  // merged pairs of the tile, for the totals (summed by a scan of the tile array: no atomics)
-  {
-    int msum = merged;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) msum += __shfl_down(msum, o);
-    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = msum;   // (s_a is free again: gf_block_scan2 ends with a barrier)
-    __syncthreads();
-    if (threadIdx.x == 0) tile_mc[blockIdx.x] = (uint32_t)(s_a[0] + s_a[1] + s_a[2] + s_a[3]);
   }
 }
 

@@ -1554,12 +1554,13 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   } cv;
   (void)al;
   const size_t o_mlen = cv.take((size_t)n * 4), o_mdiff = cv.take((size_t)n * 4), o_moff = cv.take(((size_t)n + 1) * 8);
+  const size_t o_mrank = cv.take((size_t)n * 4), o_coff = cv.take(((size_t)n + 1) * 8);
   const size_t o_mb = cv.take((size_t)(l_bytes + r_bytes) + 64), o_mq = cv.take((size_t)(l_bytes + r_bytes) + 64);
   const size_t o_cM = cv.take((size_t)n), o_c1 = cv.take((size_t)n), o_c2 = cv.take((size_t)n);
   const size_t o_mM = cv.take((size_t)n * 32), o_m1 = cv.take((size_t)n * 32), o_m2 = cv.take((size_t)n * 32);
   const size_t o_st = cv.take((size_t)n * 3), o_slot = cv.take((size_t)n * 3 * 4);
-  const size_t o_tc = cv.take((size_t)std::max(ntiles, nctiles) * 4 * 3);      // three uint32 per tile
-  const size_t o_to = cv.take((size_t)std::max(ntiles, nctiles) * 8 * 3);      // three int64 per tile
+  const size_t o_tc = cv.take((size_t)std::max(ntiles, nctiles) * 4 * 2);      // two uint32 per tile
+  const size_t o_to = cv.take((size_t)std::max(ntiles, nctiles) * 8 * 2);      // two int64 per tile
   const size_t o_scal = cv.take(256);                                          // scalars: totals of the scans, merged pairs
   const size_t o_roff = cv.take(((size_t)retry_cap + 1) * 8);
   const size_t o_rb = cv.take((size_t)retry_bytes_cap + 64), o_rq = cv.take((size_t)retry_bytes_cap + 64);
@@ -1571,13 +1572,14 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   if (rc != GF_OK) return rc;
   uint8_t* wp = (uint8_t*)base;
   int32_t* m_len = (int32_t*)(wp + o_mlen); int32_t* m_diff = (int32_t*)(wp + o_mdiff); int64_t* m_off = (int64_t*)(wp + o_moff);
+  int32_t* m_rank = (int32_t*)(wp + o_mrank); int64_t* c_off = (int64_t*)(wp + o_coff);
   uint8_t* mb = wp + o_mb; uint8_t* mq = wp + o_mq;
   uint8_t *cM = wp + o_cM, *c1 = wp + o_c1, *c2 = wp + o_c2;
   gf_seqmatch *mM = (gf_seqmatch*)(wp + o_mM), *m1 = (gf_seqmatch*)(wp + o_m1), *m2 = (gf_seqmatch*)(wp + o_m2);
   uint8_t* stt = wp + o_st; int32_t* slot_of = (int32_t*)(wp + o_slot);
   const int64_t tmax = std::max(ntiles, nctiles);
-  uint32_t *tcA = (uint32_t*)(wp + o_tc), *tcB = tcA + tmax, *tcC = tcB + tmax;
-  int64_t *toA = (int64_t*)(wp + o_to), *toB = toA + tmax, *toC = toB + tmax;
+  uint32_t *tcA = (uint32_t*)(wp + o_tc), *tcB = tcA + tmax;
+  int64_t *toA = (int64_t*)(wp + o_to), *toB = toA + tmax;
   int64_t* scal = (int64_t*)(wp + o_scal);  // [0] merged bytes, [1] retries, [2] retry bytes, [3] hits, [4] hit bytes, [5] merged pairs
   int64_t* r_off = (int64_t*)(wp + o_roff); uint8_t* rb = wp + o_rb; uint8_t* rq = wp + o_rq;
   uint8_t* cR = wp + o_cR; gf_seqmatch* mR = (gf_seqmatch*)(wp + o_mR);
@@ -1588,16 +1590,20 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   rc = gf_fast_merge_find_device(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, max_read_len,
                                  m_len, m_diff, stream);
   if (rc != GF_OK) return rc;
-  hipLaunchKernelGGL(gf_k_len_tile_sums, dim3((unsigned)nctiles), dim3(GF_CTHREADS), 0, st, (const int32_t*)m_len, n, tcA);
+  // scalars: [0] merged bytes, [1] retries, [2] retry bytes, [3] hits, [4] hit bytes, [5] merged pairs
+  hipLaunchKernelGGL(gf_k_len_tile_sums, dim3((unsigned)nctiles), dim3(GF_CTHREADS), 0, st, (const int32_t*)m_len, n, tcA, tcB);
   hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcA, nctiles, toA, scal + 0);
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcB, nctiles, toB, scal + 5);
   hipLaunchKernelGGL(gf_k_len_offsets, dim3((unsigned)nctiles), dim3(GF_CTHREADS), 0, st, (const int32_t*)m_len, n,
-                     (const int64_t*)toA, (const int64_t*)(scal + 0), m_off);
+                     (const int64_t*)toA, (const int64_t*)toB, (const int64_t*)(scal + 0), m_off, m_rank, c_off);
+  hipLaunchKernelGGL(gf_k_len_tail, dim3((unsigned)std::min<int64_t>((n + 256) / 256, 2048)), dim3(256), 0, st,
+                     (const int64_t*)(scal + 5), (const int64_t*)(scal + 0), n, c_off);
   GF_HIP(hipGetLastError());
   rc = gf_fast_merge_write_device(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, m_len, m_off,
                                   mb, mq, stream);
   if (rc != GF_OK) return rc;
   // 2. the merged reads; R1 and R2 of the pairs that did not merge (in place, the others skipped)
-  rc = map_reads_device_impl(idx, mb, m_off, n, (int32_t)std::max<int64_t>(merged_max, 1), cM, mM, stream, nullptr);
+  rc = map_reads_device_impl(idx, mb, c_off, n, (int32_t)std::max<int64_t>(merged_max, 1), cM, mM, stream, nullptr);
   if (rc != GF_OK) return rc;
   rc = map_reads_device_impl(idx, d_l_bases, d_l_offsets, n, std::max(max_read_len, 1), c1, m1, stream, m_len);
   if (rc != GF_OK) return rc;
@@ -1607,11 +1613,10 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   GfPairIn P;
   P.l_bases = (const uint8_t*)d_l_bases; P.l_quals = (const uint8_t*)d_l_quals; P.l_off = (const int64_t*)d_l_offsets;
   P.r_bases = (const uint8_t*)d_r_bases; P.r_quals = (const uint8_t*)d_r_quals; P.r_off = (const int64_t*)d_r_offsets;
-  P.m_bases = mb; P.m_quals = mq; P.m_off = m_off; P.m_len = m_len; P.m_diff = m_diff;
+  P.m_bases = mb; P.m_quals = mq; P.m_off = m_off; P.m_len = m_len; P.m_diff = m_diff; P.m_rank = m_rank;
   P.cM = cM; P.c1 = c1; P.c2 = c2; P.mM = mM; P.m1 = m1; P.m2 = m2;
   P.gene_reversed = idx->d_gene_rev; P.n_genes = idx->table.n_genes;
-  hipLaunchKernelGGL(gf_k_pair_classify, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, stt, tcA, tcB, tcC);
-  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcC, ntiles, toC, scal + 5);
+  hipLaunchKernelGGL(gf_k_pair_classify, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, stt, tcA, tcB);
   hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcA, ntiles, toA, scal + 1);
   hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcB, ntiles, toB, scal + 2);
   hipLaunchKernelGGL(gf_k_pair_retry_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, (const uint8_t*)stt,
