@@ -251,59 +251,78 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_MF_WAVES_PER_SIMD : 3) void gf_k
               const uint32_t b0 = gf_rc_word(s_pk2, end2, 0), ib0 = gf_rc_flags(s_iv2, end2, 0);
               const uint32_t pre_mask = 0x55555555u & ~ib0;
               bool done = false;
+              // the full test of one offset (rare: a random overlap passes the 16-column pre-test once in a million)
+              auto full_test = [&](int o) {
+                  // all columns of this overlap, 16 per word, R1's words cut from the tile
+                  const int olen = len1 - o;
+                  int cnt = 0, c0 = -1, c1 = -1;
+#pragma unroll
+                  for (int jj = 0; jj < PW; ++jj) {
+                    const uint32_t cm = gf_len_mask2(olen, jj);
+                    if (cm) {
+                      const uint32_t pa = pos1 + (uint32_t)o + 16u * (uint32_t)jj;
+                      const uint32_t ww = __builtin_amdgcn_alignbit(s_pk1[(pa >> 4) + 1], s_pk1[pa >> 4], 2u * (pa & 15u));
+                      const uint32_t fa = __builtin_amdgcn_alignbit(s_iv1[(pa >> 5) + 1], s_iv1[pa >> 5], pa & 31u) & 0xFFFFu;
+                      const uint32_t xx = ww ^ gf_rc_word(s_pk2, end2, jj);
+                      const uint32_t fa2 = gf_spread16(fa), fb2 = gf_rc_flags(s_iv2, end2, jj);
+                      uint32_t mm = ((xx | (xx >> 1)) | fa2 | fb2) & cm;
+                      if (both_bad) {  // both unusable: equal iff R1's byte is a literal 'N'
+                        uint32_t bb = fa2 & fb2 & cm;
+                        while (bb) {
+                          const int bit = __builtin_ctz(bb);
+                          if (s1[o + 16 * jj + (bit >> 1)] == 'N') mm &= ~(1u << bit);
+                          bb &= bb - 1;
+                        }
+                      }
+                      cnt += __popc(mm);
+                      while (mm && c1 < 0) {
+                        const int col = 16 * jj + (__builtin_ctz(mm) >> 1);
+                        if (c0 < 0) c0 = col; else c1 = col;
+                        mm &= mm - 1;
+                      }
+                    }
+                  }
+                  if (cnt > 2) return;
+                  bool ok = true;
+                  if (c0 >= 0) ok = gf_lowq_pair(q1[o + c0], q2[len2 - 1 - c0]);
+                  if (ok && c1 >= 0) ok = gf_lowq_pair(q1[o + c1], q2[len2 - 1 - c1]);
+                  if (ok) {
+                    found = olen;
+                    diff = cnt;
+                    done = true;
+                  }
+              };
+              // Offsets high to low (the smallest overlap first, read.rs:339).  Per word of R1 the 16 pre-tests are
+              // straight-line code with compile-time shifts — eight instructions each, no loop control — and their
+              // outcomes are gathered in a bit mask; the offsets outside [o_lo, o_hi] are masked out afterwards and
+              // the few survivors take the full test.  (As a runtime loop over the shifts with the range checks
+              // inside, the pre-tests were two thirds of the kernel's instructions.)
+              const bool wave_bad = __ballot(anyA != 0) != 0;
 #pragma unroll
               for (int j = PW - 1; j >= 0; --j) {
                 const uint32_t alo = A[j], ahi = j + 1 < PW ? A[j + 1] : 0u;
                 const uint32_t ilo = IA[j], ihi = j + 1 < PW ? IA[j + 1] : 0x55555555u;
-                if (16 * j <= o_hi && 16 * j + 15 >= o_lo) {
-                  for (int s = 15; s >= 0; --s) {
-                    const int o = 16 * j + s;
-                    if (done || o > o_hi || o < o_lo) continue;
-                    // first 16 columns: R1 bases o..o+15 against rc(R2) bases 0..15
-                    const uint32_t w = __builtin_amdgcn_alignbit(ahi, alo, 2u * (uint32_t)s);
-                    const uint32_t iw = __builtin_amdgcn_alignbit(ihi, ilo, 2u * (uint32_t)s);
-                    const uint32_t x = w ^ b0;
-                    const uint32_t m = ((x | (x >> 1)) | iw) & pre_mask;
-                    if (__popc(m) > 2) continue;
-                    // all columns of this overlap, 16 per word, R1's words cut from the tile
-                    const int olen = len1 - o;
-                    int cnt = 0, c0 = -1, c1 = -1;
+                const int hi_s = o_hi - 16 * j, lo_s = o_lo - 16 * j;  // this word's offsets: s in [lo_s, hi_s]
+                uint32_t vm = 0;
+                if (!done && hi_s >= 0 && lo_s <= 15) {
+                  const int sa = lo_s < 0 ? 0 : lo_s, sb = hi_s > 15 ? 15 : hi_s;
+                  vm = ((2u << sb) - 1u) & ~((1u << sa) - 1u);
+                }
+                if (__ballot(vm != 0) == 0) continue;  // (wave-uniform) nobody has an offset in this word
+                uint32_t cmask = 0;
 #pragma unroll
-                    for (int jj = 0; jj < PW; ++jj) {
-                      const uint32_t cm = gf_len_mask2(olen, jj);
-                      if (cm) {
-                        const uint32_t pa = pos1 + (uint32_t)o + 16u * (uint32_t)jj;
-                        const uint32_t ww = __builtin_amdgcn_alignbit(s_pk1[(pa >> 4) + 1], s_pk1[pa >> 4], 2u * (pa & 15u));
-                        const uint32_t fa = __builtin_amdgcn_alignbit(s_iv1[(pa >> 5) + 1], s_iv1[pa >> 5], pa & 31u) & 0xFFFFu;
-                        const uint32_t xx = ww ^ gf_rc_word(s_pk2, end2, jj);
-                        const uint32_t fa2 = gf_spread16(fa), fb2 = gf_rc_flags(s_iv2, end2, jj);
-                        uint32_t mm = ((xx | (xx >> 1)) | fa2 | fb2) & cm;
-                        if (both_bad) {  // both unusable: equal iff R1's byte is a literal 'N'
-                          uint32_t bb = fa2 & fb2 & cm;
-                          while (bb) {
-                            const int bit = __builtin_ctz(bb);
-                            if (s1[o + 16 * jj + (bit >> 1)] == 'N') mm &= ~(1u << bit);
-                            bb &= bb - 1;
-                          }
-                        }
-                        cnt += __popc(mm);
-                        while (mm && c1 < 0) {
-                          const int col = 16 * jj + (__builtin_ctz(mm) >> 1);
-                          if (c0 < 0) c0 = col; else c1 = col;
-                          mm &= mm - 1;
-                        }
-                      }
-                    }
-                    if (cnt > 2) continue;
-                    bool ok = true;
-                    if (c0 >= 0) ok = gf_lowq_pair(q1[o + c0], q2[len2 - 1 - c0]);
-                    if (ok && c1 >= 0) ok = gf_lowq_pair(q1[o + c1], q2[len2 - 1 - c1]);
-                    if (ok) {
-                      found = olen;
-                      diff = cnt;
-                      done = true;
-                    }
-                  }
+                for (int s = 15; s >= 0; --s) {
+                  // first 16 columns: R1 bases o..o+15 against rc(R2) bases 0..15
+                  uint32_t t = __builtin_amdgcn_alignbit(ahi, alo, 2u * (uint32_t)s) ^ b0;
+                  t |= t >> 1;
+                  if (wave_bad) t |= __builtin_amdgcn_alignbit(ihi, ilo, 2u * (uint32_t)s);
+                  cmask = (cmask << 1) | (__popc(t & pre_mask) <= 2 ? 1u : 0u);
+                }
+                cmask &= vm;  // (bit s = offset 16 j + s)
+                while (cmask != 0 && !done) {
+                  const int s = 31 - __builtin_clz(cmask);
+                  cmask &= ~(1u << s);
+                  full_test(16 * j + s);
                 }
               }
             }
