@@ -952,7 +952,15 @@ static int stage_and_map(gf_index* mix, HostLane& L, const char* bases, const in
 // copies altogether: the reads are written to the lane's pinned block, ONE launch of the exact
 // wave-per-read kernel fetches them over the link and writes its result back to the same block.
 // (The batch route is an H2D copy, five launches and a D2H copy for the same answer.)
-static const int64_t GF_SMALL_CALL_READS = 64;
+static int64_t small_call_reads() {
+  static const int64_t v = [] {
+    int64_t d = 64;
+    if (const char* e = getenv("GF_SMALL_CALL_READS")) d = std::max<int64_t>(0, atoll(e));  // experiments
+    return d;
+  }();
+  return v;
+}
+#define GF_SMALL_CALL_READS small_call_reads()
 
 static int map_small(gf_index* mix, HostLane& L, const char* bases, const int64_t* offsets, int64_t n,
                      const uint8_t** out_counts, const gf_seqmatch** out_matches) {
