@@ -75,35 +75,64 @@ __device__ __forceinline__ uint64_t* gf_find_slot(uint64_t* slots, uint32_t nbuc
   return nullptr;
 }
 
-// FILL pass: store the site code of one occurrence.
-// For a key with exactly one site the site's "unique" flag in gdu is set here too (the flag
-// word of site code lin is gdu[2 * (lin >> 4) + 1], bit 2 * (lin & 15)): the slot is in hand.
-__device__ __forceinline__ void gf_fill_site(uint64_t* slots, uint32_t nbuckets, uint32_t* dupes, uint32_t* gdu,
-                                             uint32_t key, uint32_t lin) {
+// FILL pass: store the site code of one occurrence; true when the key has exactly this one site (the
+// caller then sets the site's "unique" flag in gdu, a wavefront's flags at a time).
+__device__ __forceinline__ bool gf_fill_site(uint64_t* slots, uint32_t nbuckets, uint32_t* dupes, uint32_t key, uint32_t lin) {
   uint64_t* s = gf_find_slot(slots, nbuckets, key);
-  if (!s) return;
+  if (!s) return false;
   uint32_t* valp = (uint32_t*)s;  // little-endian: low word = val
   uint32_t val = *valp;
   uint32_t type = (val & GF_VAL_LOW) >> GF_TYPE_SHIFT;
   if (type == GF_TYPE_UNIQUE) {
     // exactly one occurrence => exactly one writer
     *valp = (val & GF_VAL_OVF) | (GF_TYPE_UNIQUE << GF_TYPE_SHIFT) | (lin & GF_LIN_MASK);
-    atomicOr(gdu + 2 * (lin >> 4) + 1, 1u << (2u * (lin & 15u)));
+    return true;
   } else if (type == GF_TYPE_DUPES) {
     uint32_t cnt = (val >> GF_DUPE_COUNT_SHIFT) & 7u;
     uint32_t start = val & GF_DUPE_START_MASK;
     for (uint32_t k = 0; k < cnt; ++k)
       if (atomicCAS(dupes + start + k, GF_DUPE_EMPTY, lin) == GF_DUPE_EMPTY) break;
   }
+  return false;
+}
+
+// The "unique" flags of a wavefront's sites (flag of site code lin: gdu[2 * (lin >> 4) + 1], bit 2 * (lin & 15)).
+// The lanes of a wavefront hold consecutive site codes, 16 to a flag word: the lanes of a word OR their bits
+// together with shuffles and the first of them issues the one atomic (an atomic per site was 29 M of them on a
+// cancer-sized gene set, sixteen neighbours to the same address).  Called by all 64 lanes.
+__device__ __forceinline__ void gf_wave_set_unique(uint32_t* gdu, bool has, uint32_t lin) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wi = has ? (lin >> 4) : 0xFFFFFFFFu;
+  uint32_t v = has ? 1u << (2u * (lin & 15u)) : 0u;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    const uint32_t y = __shfl_down(v, o), wy = __shfl_down(wi, o);
+    if (lane + o < 64 && wy == wi) v |= y;
+  }
+  const uint32_t wp = __shfl_up(wi, 1);
+  if (v && (lane == 0 || wp != wi)) atomicOr(gdu + 2 * (size_t)wi + 1, v);
+}
+
+// One canonical 14-mer into the presence filter: most bit pairs of a repeated 14-mer are set already, so
+// look before the atomic.
+__device__ __forceinline__ void gf_bloom_insert(uint32_t* bloom, uint32_t nwords, uint32_t s14) {
+  const uint32_t h = GF_BLOOM_HASH((s14));
+  uint32_t* w = bloom + GF_BLOOM_WORD(h, nwords);
+  const uint32_t b = GF_BLOOM_BITS(h);
+  if ((__builtin_nontemporal_load(w) & b) != b) atomicOr(w, b);
 }
 
 // One block = one tile of GF_TILE_BASES window starts.  Phase 1 packs the tile's
-// ASCII bases (+15 halo) into a 2-bit stream and an invalid-bit stream in LDS with
+// ASCII bases (+ halo) into a 2-bit stream and an invalid-bit stream in LDS with
 // coalesced 16-byte loads; phase 2 cuts the windows out of LDS.
+// The FILL pass also sets the sites' "unique" flags and fills the presence filter (bloom != nullptr): every key's
+// first and last 14 bases in canonical form (gf_table.h) — a window enters its first 14 bases, and its last 14
+// only where window + 2, whose first 14 they are, has no key; both strands of a window share the canonical forms.
 template <int MODE>
 __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_sites(GfGenes G, uint64_t* slots,
                                                                      uint32_t nbuckets,
-                                                                     uint32_t* dupes, uint32_t* gdu) {
+                                                                     uint32_t* dupes, uint32_t* gdu,
+                                                                     uint32_t* bloom, uint32_t bloom_words) {
   __shared__ uint32_t s_codes[GF_TILE_BASES / 16 + 2];
   __shared__ uint32_t s_inv[GF_TILE_BASES / 32 + 2];
   const uint32_t t0 = blockIdx.x * GF_TILE_BASES;
@@ -128,99 +157,121 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_sites(GfGenes G, 
   }
   __syncthreads();
 
-  for (int l = tid; l < GF_TILE_BASES; l += GF_INDEX_THREADS) {
-    uint32_t g = t0 + (uint32_t)l;
-    if (g >= G.total) break;
-    uint32_t flags = gf_flags16(s_inv[l >> 5], s_inv[(l >> 5) + 1], (uint32_t)l);
-    if (flags) continue;
-    // gene of g: last c with gene_off[c] <= g
-    int lo = 0, hi = G.n_genes;  // invariant gene_off[lo] <= g < gene_off[hi]
-    while (hi - lo > 1) {
-      int mid = (lo + hi) >> 1;
-      if (G.gene_off[mid] <= g) lo = mid; else hi = mid;
-    }
-    uint32_t f = g - G.gene_off[lo];
-    uint32_t len = G.gene_off[lo + 1] - G.gene_off[lo];
-    if (f + GF_KMER > len) continue;  // window runs past the gene
-    uint32_t key = gf_window(s_codes[l >> 4], s_codes[(l >> 4) + 1], (uint32_t)l);
-    if (f + GF_KMER < len) {  // forward windows 0 .. len-17 (indexer.rs:188)
-      if (MODE == GF_MODE_COUNT) gf_insert_count(slots, nbuckets, key);
-      else gf_fill_site(slots, nbuckets, dupes, gdu, key, G.lin_base[lo] + f);
-    }
-    if (f >= 1) {  // reverse windows i = len-16-f in 0 .. len-17
-      uint32_t rkey = gf_revcomp_key(key);
-      if (MODE == GF_MODE_COUNT) gf_insert_count(slots, nbuckets, rkey);
-      else gf_fill_site(slots, nbuckets, dupes, gdu, rkey, G.lin_base[lo] - (f + 15u));
-    }
-  }
-}
-
-// Publish both strands of the genes in site-code space (gdu, layout: gf_table.h), used by the
-// diagonal verification of the mapping kernels.  gdu is zero-filled by the host; bits are
-// OR-ed in.  (The per-site uniqueness flags of gdu are set by the FILL pass.)
-__global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_strands(GfGenes G, uint64_t* slots,
-                                                                       uint32_t nbuckets,
-                                                                       uint32_t* __restrict__ gdu) {
-  __shared__ uint32_t s_codes[GF_TILE_BASES / 16 + 2];
-  __shared__ uint32_t s_inv[GF_TILE_BASES / 32 + 2];
-  const uint32_t t0 = blockIdx.x * GF_TILE_BASES;
-  const int tid = threadIdx.x;
-  for (int ch = tid; ch < GF_TILE_BASES / 16 + 1; ch += GF_INDEX_THREADS) {
-    uint4 q = *(const uint4*)(G.cat + (size_t)t0 + 16u * ch);
-    uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
-    gf_convert4(q.x, c0, i0);
-    gf_convert4(q.y, c1, i1);
-    gf_convert4(q.z, c2, i2);
-    gf_convert4(q.w, c3, i3);
-    s_codes[ch] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-    ((uint16_t*)s_inv)[ch] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
-  }
-  if (tid == 0) {
-    s_codes[GF_TILE_BASES / 16 + 1] = 0;
-    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 1] = 0xFFFF;
-    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 2] = 0xFFFF;
-    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 3] = 0xFFFF;
-  }
-  __syncthreads();
-  for (int l = tid; l < GF_TILE_BASES; l += GF_INDEX_THREADS) {
+  for (int l0 = 0; l0 < GF_TILE_BASES; l0 += GF_INDEX_THREADS) {  // (every lane of a wave stays in the loop)
+    const int l = l0 + tid;
     const uint32_t g = t0 + (uint32_t)l;
-    if (g >= G.total) break;
-    int lo = 0, hi = G.n_genes;
-    while (hi - lo > 1) {
-      int mid = (lo + hi) >> 1;
-      if (G.gene_off[mid] <= g) lo = mid; else hi = mid;
+    bool fwd = false, rev = false, next_has = false;
+    uint32_t key = 0, lin_f = 0, lin_r = 0;
+    if (g < G.total) {
+      // the invalid-base flags of bases l .. l+31 (the halo chunk beyond the tile is flagged invalid from
+      // base TILE + 16 on, the one after it entirely)
+      const uint32_t sh = (uint32_t)l & 31u;
+      const uint32_t lo_w = s_inv[l >> 5], hi_w = s_inv[(l >> 5) + 1];
+      const uint32_t inv = sh ? ((lo_w >> sh) | (hi_w << (32u - sh))) : lo_w;
+      if ((inv & 0xFFFFu) == 0) {
+        // gene of g: last c with gene_off[c] <= g
+        int lo = 0, hi = G.n_genes;  // invariant gene_off[lo] <= g < gene_off[hi]
+        while (hi - lo > 1) {
+          int mid = (lo + hi) >> 1;
+          if (G.gene_off[mid] <= g) lo = mid; else hi = mid;
+        }
+        const uint32_t f = g - G.gene_off[lo];
+        const uint32_t len = G.gene_off[lo + 1] - G.gene_off[lo];
+        if (f + GF_KMER <= len) {  // the window lies inside the gene
+          key = gf_window(s_codes[l >> 4], s_codes[(l >> 4) + 1], (uint32_t)l);
+          fwd = f + GF_KMER < len;  // forward windows 0 .. len-17 (indexer.rs:188)
+          rev = f >= 1;             // reverse windows i = len-16-f in 0 .. len-17
+          lin_f = G.lin_base[lo] + f;
+          lin_r = G.lin_base[lo] - (f + 15u);
+          // window + 2 has a key of its own (it then enters the 14 bases the two share).  In the tile's last
+          // two windows the flags of its last bases are beyond the halo: "no" there costs one more look-up.
+          next_has = ((inv >> 2) & 0xFFFFu) == 0 && f + 2 + GF_KMER <= len && l + 2 + GF_KMER <= GF_TILE_BASES + 16;
+        }
+      }
     }
-    const uint32_t f = g - G.gene_off[lo];
-    const uint32_t base = G.lin_base[lo];
-    // this base on both strands (invalid bases keep code 0: their windows carry no ub bit)
-    const uint32_t code = (s_codes[l >> 4] >> (2 * (l & 15))) & 3u;
-    const bool bad = (s_inv[l >> 5] >> (l & 31)) & 1u;
-    if (!bad) {
-      const uint32_t pf = base + f;
-      if (code) atomicOr(gdu + 2 * (pf >> 4), code << (2 * (pf & 15u)));
-      if (f >= 1) {
-        const uint32_t pr = base - f;  // reverse-complement base j = len-1-f at base + 1 - len + j
-        atomicOr(gdu + 2 * (pr >> 4), (code ^ 2u) << (2 * (pr & 15u)));
+    if (MODE == GF_MODE_COUNT) {
+      if (fwd) gf_insert_count(slots, nbuckets, key);
+      if (rev) gf_insert_count(slots, nbuckets, gf_revcomp_key(key));
+    } else {
+      const bool uf = fwd && gf_fill_site(slots, nbuckets, dupes, key, lin_f);
+      const bool ur = rev && gf_fill_site(slots, nbuckets, dupes, gf_revcomp_key(key), lin_r);
+      gf_wave_set_unique(gdu, uf, lin_f);
+      gf_wave_set_unique(gdu, ur, lin_r);
+      if (bloom && (fwd || rev)) {
+        gf_bloom_insert(bloom, bloom_words, key & 0x0FFFFFFFu);
+        if (!next_has) gf_bloom_insert(bloom, bloom_words, key >> 4);
       }
     }
   }
 }
 
-// presence filter over the last and the first 14 bases of every key (gf_table.h: bloom)
-__global__ void gf_k_build_bloom(const uint64_t* slots, uint64_t nslots, uint32_t* bloom, uint32_t nwords) {
-  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots;
-       s += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t v = slots[s];
-    if (((uint32_t)v & GF_VAL_LOW) == 0) continue;
-    const uint32_t key = (uint32_t)(v >> 32);
-    const uint32_t ha = GF_BLOOM_HASH((key >> 4)), hb = GF_BLOOM_HASH((key & 0x0FFFFFFFu));
-    // neighbouring keys share their 14-mers, so most bit pairs are set already: look before the atomic
-    uint32_t* wa = bloom + GF_BLOOM_WORD(ha, nwords);
-    uint32_t* wb = bloom + GF_BLOOM_WORD(hb, nwords);
-    const uint32_t ba = GF_BLOOM_BITS(ha), bb = GF_BLOOM_BITS(hb);
-    if ((__builtin_nontemporal_load(wa) & ba) != ba) atomicOr(wa, ba);
-    if ((__builtin_nontemporal_load(wb) & bb) != bb) atomicOr(wb, bb);
+// Both strands of the genes in site-code space (the even words of gdu, layout: gf_table.h), used by the diagonal
+// verification of the mapping kernels.  A thread writes one word = 16 consecutive site codes of one gene's
+// region [lin_base - len + 1, lin_base + len - 1]: codes >= lin_base are the forward bases f = code - lin_base,
+// codes below it the complements of the bases f = lin_base - code — sixteen bytes of the gene per strand, one
+// unaligned load each, converted and (for the reverse strand) turned round.  Bases other than A/C/G/T keep
+// code 0, like the gaps between the regions.  (The first form took every base to its two words with atomicOr:
+// sixteen neighbouring lanes to the same address, 1.1 ms on a cancer-sized gene set.)
+// 16 bases at p (any alignment) as 2-bit fields; valid2 = 3 in the fields of the first `count` bases that are A/C/G/T
+__device__ __forceinline__ uint32_t gf_codes16(const uint8_t* p, uint32_t count, uint32_t& valid2) {
+  uint4 q;
+  __builtin_memcpy(&q, p, 16);
+  uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+  gf_convert4(q.x, c0, i0);
+  gf_convert4(q.y, c1, i1);
+  gf_convert4(q.z, c2, i2);
+  gf_convert4(q.w, c3, i3);
+  uint32_t m = (i0 | (i1 << 4) | (i2 << 8) | (i3 << 12)) & 0xFFFFu;
+  if (count < 16) m |= (0xFFFFu << count) & 0xFFFFu;
+  // spread the 16 invalid bits over the 2-bit fields
+  m = (m | (m << 8)) & 0x00FF00FFu;
+  m = (m | (m << 4)) & 0x0F0F0F0Fu;
+  m = (m | (m << 2)) & 0x33333333u;
+  m = (m | (m << 1)) & 0x55555555u;
+  valid2 = ~(m | (m << 1));
+  return c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+}
+
+__global__ __launch_bounds__(256) void gf_k_index_strands(GfGenes G, const uint32_t* __restrict__ lin_hi,
+                                                          uint32_t* __restrict__ gdu, uint32_t gd_words) {
+  const uint32_t W = blockIdx.x * blockDim.x + threadIdx.x;
+  if (W >= gd_words) return;
+  const uint32_t p0 = 16u * W;
+  uint32_t out = 0;
+  // gene whose slice of the space [lin_hi[c-1], lin_hi[c]) holds p0 (the regions are GF_LIN_PAD apart: a word
+  // never holds codes of two genes)
+  int lo = -1, hi = G.n_genes;  // invariant lin_hi[lo] <= p0 < lin_hi[hi]  (lin_hi[-1] = 0, lin_hi[n] = inf)
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (lin_hi[mid] <= p0) lo = mid; else hi = mid;
   }
+  const int c = hi;
+  if (c < G.n_genes) {
+    const uint32_t base = G.lin_base[c];
+    const uint32_t goff = G.gene_off[c];
+    const uint32_t len = G.gene_off[c + 1] - goff;
+    const uint32_t p1 = p0 + 15u;
+    if (len > 0) {
+      // forward strand: codes max(p0, base) .. min(p1, base + len - 1)
+      if (p1 >= base && p0 <= base + len - 1u) {
+        const uint32_t a = p0 > base ? p0 : base, b = p1 < base + len - 1u ? p1 : base + len - 1u;
+        uint32_t ok2;
+        const uint32_t w = gf_codes16(G.cat + goff + (a - base), b - a + 1u, ok2) & ok2;
+        out |= w << (2u * (a - p0));
+      }
+      // reverse strand: codes max(p0, base - len + 1) .. min(p1, base - 1), f = base - code
+      if (len > 1 && p0 + 1u <= base && p1 + len >= base + 1u) {
+        const uint32_t a = p0 + len > base + 1u ? p0 : base + 1u - len, b = p1 < base - 1u ? p1 : base - 1u;
+        const uint32_t cnt = b - a + 1u, f_lo = base - b;
+        uint32_t ok2;
+        uint32_t w = gf_codes16(G.cat + goff + f_lo, cnt, ok2);  // field i = base f_lo + i
+        w = (w ^ 0xAAAAAAAAu) & ok2;                              // complemented; other bases and the rest: 0
+        w = gf_field_reverse(w) >> (2u * (16u - cnt));      // field k = base f_lo + cnt-1-k = base - (a + k)
+        out |= w << (2u * (a - p0));
+      }
+    }
+  }
+  gdu[2 * (size_t)W] = out;
 }
 
 // stats[0]=n_sites [1]=n_keys [2]=n_unique [3]=n_dupe_keys [4]=n_high [5]=n_dupe_sites

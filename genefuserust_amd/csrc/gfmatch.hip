@@ -421,36 +421,26 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
 
   const int sweep_grid = (int)std::min<uint64_t>((nslots + 255) / 256, (uint64_t)ix->n_cus * 16);
   unsigned long long stats[8] = {0};
+  // both strands in site-code space: needs nothing from the table
+  hipLaunchKernelGGL(gf_k_index_strands, dim3((unsigned)((gd_words + 255) / 256)), dim3(256), 0, 0, G,
+                     (const uint32_t*)ix->d_lin_hi, ix->d_gdu, (uint32_t)gd_words);
+  GF_HIP(hipGetLastError());
   if (ntiles > 0) {
     hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_COUNT>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
-                       ix->d_slots, nbuckets, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                       ix->d_slots, nbuckets, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     GF_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(gf_k_classify_count, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
   GF_HIP(hipGetLastError());
   GF_HIP(hipMemcpy(stats, d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
+  lap("strands, count pass, statistics");
   const uint64_t n_dupe_sites = stats[5];
   if (n_dupe_sites > (uint64_t)GF_DUPE_START_MASK)
     return fail(GF_ERR_CAPACITY, "too many duplicated sites for the 26-bit duplicate index");
   GF_HIP(hipMalloc((void**)&ix->d_dupes, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t)));
   GF_HIP(hipMemset(ix->d_dupes, 0xFF, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t)));
-  hipLaunchKernelGGL(gf_k_classify_assign, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
-  GF_HIP(hipGetLastError());
-  if (ntiles > 0) {
-    hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_FILL>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
-                       ix->d_slots, nbuckets, ix->d_dupes, ix->d_gdu);
-    GF_HIP(hipGetLastError());
-  }
-  hipLaunchKernelGGL(gf_k_sort_dupes, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_dupes);
-  GF_HIP(hipGetLastError());
-  if (ntiles > 0) {
-    hipLaunchKernelGGL(gf_k_index_strands, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G, ix->d_slots, nbuckets,
-                       ix->d_gdu);
-    GF_HIP(hipGetLastError());
-  }
-  lap("table kernels");
-  // presence filter over canonical 14-mers.  Indexes up to ~14 M keys: <= GF_BLOOM_KIB (default
-  // 3 MiB) so that it lives in every XCD's L2, and seed+verify runs the filter pass for reads
+  // presence filter over canonical 14-mers, filled by the FILL pass.  Indexes up to ~14 M keys: <= GF_BLOOM_KIB
+  // (default 3 MiB) so that it lives in every XCD's L2, and seed+verify runs the filter pass for reads
   // without a candidate diagonal itself.  Up to ~30 M keys: 2.2 bits per key, up to
   // GF_BLOOM_MID_KIB (default 8 MiB) — no longer L2-resident, but still mostly L2 hits: used for
   // the seeds and by the filter kernel, which asks it half by half so that the half in use does
@@ -487,13 +477,21 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
       bloom_words = (uint32_t)words;
       GF_HIP(hipMalloc((void**)&ix->d_bloom, (size_t)bloom_words * sizeof(uint32_t)));
       GF_HIP(hipMemset(ix->d_bloom, 0, (size_t)bloom_words * sizeof(uint32_t)));
-      hipLaunchKernelGGL(gf_k_build_bloom, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_bloom,
-                         bloom_words);
-      GF_HIP(hipGetLastError());
     }
   }
+  hipLaunchKernelGGL(gf_k_classify_assign, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
+  GF_HIP(hipGetLastError());
+  lap("list assignment");
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_FILL>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
+                       ix->d_slots, nbuckets, ix->d_dupes, ix->d_gdu, ix->d_bloom, bloom_words);
+    GF_HIP(hipGetLastError());
+  }
+  lap("fill pass (sites, unique flags, filter)");
+  hipLaunchKernelGGL(gf_k_sort_dupes, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_dupes);
+  GF_HIP(hipGetLastError());
   GF_HIP(hipDeviceSynchronize());
-  lap("filter");
+  lap("list sort");
 
   ix->table.slots = ix->d_slots;
   ix->table.bloom = ix->d_bloom;
