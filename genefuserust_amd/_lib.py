@@ -165,6 +165,8 @@ def lib() -> C.CDLL:
     L.gf_scan_pairs_device.restype = C.c_int
     L.gf_segment_mask_test.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
     L.gf_segment_mask_test.restype = C.c_int
+    L.gf_index_export.argtypes = [vp, i32, vp, i64]
+    L.gf_index_export.restype = i64
     L.gf_index_trim.argtypes = [vp]
     L.gf_index_trim.restype = C.c_int
     L.gf_stream_open.argtypes = [vp, i64, i64, i32, C.POINTER(vp)]

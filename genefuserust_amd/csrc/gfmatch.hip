@@ -1814,6 +1814,30 @@ int gf_stream_collect(gf_stream* s, gf_hit* out_hits, int64_t cap, int64_t* out_
   return GF_OK;
 }
 
+int64_t gf_index_export(const gf_index* idx, int32_t what, void* out, int64_t cap) {
+  if (!idx || cap < 0) return fail(GF_ERR_ARG, "null argument");
+  const void* src = nullptr;
+  int64_t bytes = 0;
+  if (what == GF_EXPORT_GDU) {
+    src = idx->d_gdu;
+    bytes = 8 * (int64_t)idx->table.gd_words;
+  } else if (what == GF_EXPORT_FILTER) {
+    src = idx->d_bloom;
+    bytes = 4 * (int64_t)idx->table.bloom_words;
+  } else if (what == GF_EXPORT_LIN_BASE) {
+    src = idx->d_lin_base;
+    bytes = 4 * (int64_t)idx->table.n_genes;
+  } else {
+    return fail(GF_ERR_ARG, "gf_index_export: unknown array");
+  }
+  if (out && bytes > 0 && cap > 0) {
+    DeviceGuard guard(idx->device);
+    GF_HIP(hipDeviceSynchronize());
+    GF_HIP(hipMemcpy(out, src, (size_t)std::min<int64_t>(cap, bytes), hipMemcpyDeviceToHost));
+  }
+  return bytes;
+}
+
 int gf_index_trim(gf_index* idx) {
   if (!idx) return fail(GF_ERR_ARG, "null index");
   DeviceGuard guard(idx->device);

@@ -113,6 +113,17 @@ int gf_index_info_get(const gf_index* idx, gf_index_info* out);
  * index's device (they grow again on demand); gf_index_free frees what the index owns. */
 int gf_index_trim(gf_index* idx);
 
+/* Test hook: one of the index's derived device arrays, copied to the host as it is.  Returns its size in
+ * bytes (or a negative error) and copies min(cap, size) bytes to out when out != NULL.
+ *   GF_EXPORT_GDU      uint32 pairs, one per 16 site codes: (both strands of the genes as 2-bit codes A0 C1 T2 G3,
+ *                      the sites' "only site of its key" flags on the even bits)
+ *   GF_EXPORT_FILTER   the presence filter over canonical 14-mers, uint32 words
+ *   GF_EXPORT_LIN_BASE uint32 per gene: the site code of its forward base 0 (forward base f = code + f,
+ *                      reverse-strand base f = code - f)
+ * tests/test_index_arrays.py rebuilds all three from the gene slices and compares every word. */
+enum { GF_EXPORT_GDU = 0, GF_EXPORT_FILTER = 1, GF_EXPORT_LIN_BASE = 2 };
+int64_t gf_index_export(const gf_index* idx, int32_t what, void* out, int64_t cap);
+
 /* Indexer.m_fusion_seq[c] (indexer.rs:77, :170; read by fusion_mapper.rs:230,
  * :439-452): the upper-cased gene slice, kept on the host.  Returns its length
  * (or a negative error) and copies min(cap, length) bytes to out when out != NULL. */

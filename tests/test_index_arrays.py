@@ -1,0 +1,149 @@
+"""The index's derived device arrays, word by word: the genes of both strands in site-code space, the
+"only site of its key" flags and the presence filter over canonical 14-mers (csrc/gf_index_kernels.h,
+layout in csrc/gf_table.h) are what the mapping kernels verify candidates against — a wrong word there is
+hidden from the mapping tests wherever the exact kernel repairs the result.  Here they are rebuilt on the
+host from the gene slices alone, following Indexer::make_index / index_contig (src/core/indexer.rs:122-250:
+forward windows 0..len-17, reverse-complement windows 1..len-16, a window with a base other than A/C/G/T
+has no key, lower case is upper-cased first) and compared with gf_index_export.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CODE = {65: 0, 67: 1, 84: 2, 71: 3}   # A C T G: (ascii >> 1) & 3; complement = code ^ 2
+M32 = 0xFFFFFFFF
+
+
+def _export(ix, what):
+    from genefuserust_amd import _lib
+    L, h = _lib.lib(), ix._handle()
+    n = L.gf_index_export(h, what, None, 0)
+    assert n >= 0
+    buf = np.zeros(max(n // 4, 1), dtype=np.uint32)
+    assert L.gf_index_export(h, what, buf.ctypes.data, n) == n
+    return buf[: n // 4]
+
+
+def _field_reverse(x):
+    r = 0
+    for k in range(16):
+        r |= ((x >> (2 * k)) & 3) << (2 * (15 - k))
+    return r
+
+
+def _canon14(x):
+    r = (_field_reverse(x) >> 4) ^ 0x0AAAAAAA
+    return min(r, x)
+
+
+def _filter_bits(s14, nwords):
+    h = (_canon14(s14) * 0x9E3779B1) & M32
+    m = h ^ (h >> 15)
+    return (h * nwords) >> 32, (1 << (m & 31)) | (1 << ((m >> 5) & 31))
+
+
+def _genes(rng):
+    """Gene slices around every boundary of the build: shorter than a window, exactly one window, one key per
+    strand, tile edges (4096 window starts per block), runs of N, lower case, repeats (2..5-fold and
+    >= 6-fold keys), a gene that repeats another one's stretch."""
+    def rnd(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n))
+    g = [rnd(n) for n in (5, 16, 17, 18, 31, 33, 4095, 4096, 4097, 4111, 4113, 9000)]
+    g.append(b"")
+    a = bytearray(rnd(3000))
+    a[100:103] = b"NNN"
+    a[1500] = ord("n")
+    a[2999] = ord("N")
+    a[0] = ord("R")
+    g.append(bytes(a))
+    g.append(rnd(700).lower())
+    unit = rnd(40)
+    g.append(rnd(50) + unit * 3 + rnd(60) + unit + rnd(10))          # 2..5-fold keys
+    g.append(rnd(20) + b"AC" * 40 + rnd(20) + rnd(30) * 8)           # >= 6-fold keys
+    g.append(g[11][1000:1400] + rnd(100))                            # shares 400 bases with another gene
+    g.append(b"A" * 64)                                              # its own reverse complement is all T
+    g.append(b"ACGT" * 16)                                           # palindromic windows: forward key == reverse key
+    return g
+
+
+def _expected(genes, lin_base, gd_words, filter_words):
+    even = np.zeros(gd_words, dtype=np.uint64)
+    flags = np.zeros(gd_words, dtype=np.uint64)
+    sites = {}   # key (int, base 0 in the low bits) -> list of site codes
+    for c, raw in enumerate(genes):
+        s = raw.upper()
+        n, B = len(s), int(lin_base[c])
+        codes = [CODE.get(ch, -1) for ch in s]
+        for f, cd in enumerate(codes):
+            if cd < 0:
+                continue
+            p = B + f
+            even[p >> 4] |= cd << (2 * (p & 15))
+            if f >= 1:
+                p = B - f
+                even[p >> 4] |= (cd ^ 2) << (2 * (p & 15))
+        for f in range(0, n - 15):
+            w = codes[f:f + 16]
+            if min(w) < 0:
+                continue
+            key = sum(cd << (2 * k) for k, cd in enumerate(w))
+            if f + 16 < n:                 # forward windows 0 .. len-17
+                sites.setdefault(key, []).append(B + f)
+            if f >= 1:                     # reverse-complement windows
+                rkey = _field_reverse(key) ^ 0xAAAAAAAA
+                sites.setdefault(rkey, []).append(B - (f + 15))
+    filt = np.zeros(max(filter_words, 1), dtype=np.uint64)
+    for key, where in sites.items():
+        if len(where) == 1:
+            p = where[0]
+            flags[p >> 4] |= 1 << (2 * (p & 15))
+        for s14 in (key & 0x0FFFFFFF, key >> 4):
+            w, b = _filter_bits(s14, filter_words)
+            filt[w] |= b
+    return even.astype(np.uint32), flags.astype(np.uint32), filt.astype(np.uint32), sites
+
+
+def test_strands_flags_and_filter_word_by_word(gpu_device):
+    from genefuserust_amd import Indexer, _lib
+    rng = np.random.default_rng(20260)
+    genes = _genes(rng)
+    ix = Indexer.from_gene_slices(genes)
+    ix.make_index()
+    try:
+        gdu = _export(ix, 0)
+        filt = _export(ix, 1)
+        lin_base = _export(ix, 2)
+        assert lin_base.shape[0] == len(genes) and gdu.shape[0] % 2 == 0
+        gd_words = gdu.shape[0] // 2
+        even, flags, want_filter, sites = _expected(genes, lin_base, gd_words, filt.shape[0])
+        got_even, got_flags = gdu[0::2], gdu[1::2]
+        bad = np.nonzero(got_even != even)[0]
+        assert bad.size == 0, ("strand words differ", bad[:5], [hex(int(got_even[i])) for i in bad[:5]],
+                               [hex(int(even[i])) for i in bad[:5]])
+        bad = np.nonzero(got_flags != flags)[0]
+        assert bad.size == 0, ("unique flags differ", bad[:5], [hex(int(got_flags[i])) for i in bad[:5]],
+                               [hex(int(flags[i])) for i in bad[:5]])
+        assert int(flags.astype(np.uint64).sum()) > 0 and int((flags & 0xAAAAAAAA).sum()) == 0
+        # the filter holds exactly the canonical 14-mers of the keys: no missing bit (a false negative would
+        # drop reads), no bit more than the build rule gives
+        bad = np.nonzero(filt != want_filter)[0]
+        assert bad.size == 0, ("filter words differ", bad[:5])
+        info = ix.info()
+        assert info["n_keys"] == len(sites) and info["n_unique"] == sum(1 for v in sites.values() if len(v) == 1)
+        assert info["n_high_keys"] == sum(1 for v in sites.values() if len(v) >= 6) and info["n_high_keys"] > 0
+        assert info["n_dupe_keys"] == sum(1 for v in sites.values() if 2 <= len(v) <= 5) and info["n_dupe_keys"] > 0
+    finally:
+        ix.close()
+
+
+def test_export_rejects_unknown_array(gpu_device):
+    from genefuserust_amd import Indexer, _lib
+    ix = Indexer.from_gene_slices([b"ACGTTGCA" * 8])
+    ix.make_index()
+    try:
+        assert _lib.lib().gf_index_export(ix._handle(), 7, None, 0) < 0
+    finally:
+        ix.close()
