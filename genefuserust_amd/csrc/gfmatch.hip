@@ -83,6 +83,99 @@ struct DevBuf {
   }
 };
 
+// Device blocks of freed indexes, kept for the next gf_index_build on the same device: in multi-CSV mode an
+// index lives for one pass over the reads (fusion_scan.rs:62-188), and hipMalloc + hipFree of its arrays cost
+// 1.3 ms per rebuild next to 2-6 ms of build kernels.  A request takes the smallest cached block that is large
+// enough and at most a quarter larger; at most GF_INDEX_CACHE_MIB (default 2048) stay cached per process,
+// gf_index_trim frees them.
+struct BlockCache {
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, void*> idle;  // (device, bytes) -> block
+  std::map<void*, size_t> size_of;                    // every block handed out or idle -> its size
+  size_t idle_bytes = 0;
+};
+BlockCache& block_cache() {
+  static BlockCache* c = new BlockCache();  // (never destroyed: no hipFree after the runtime has shut down)
+  return *c;
+}
+size_t block_cache_limit() {
+  static const size_t lim = [] {
+    const char* e = getenv("GF_INDEX_CACHE_MIB");
+    return (size_t)(e ? std::max(0l, atol(e)) : 2048l) << 20;
+  }();
+  return lim;
+}
+hipError_t block_alloc(int dev, void** out, size_t bytes) {
+  bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
+  BlockCache& C = block_cache();
+  {
+    std::lock_guard<std::mutex> g(C.mu);
+    auto it = C.idle.lower_bound({dev, bytes});
+    if (it != C.idle.end() && it->first.first == dev && it->first.second <= bytes + bytes / 4 + (64u << 10)) {
+      *out = it->second;
+      C.idle_bytes -= it->first.second;
+      C.idle.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {  // give the idle blocks back and try once more
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> g(C.mu);
+      for (auto it = C.idle.begin(); it != C.idle.end();)
+        if (it->first.first == dev) {
+          drop.push_back(it->second);
+          C.idle_bytes -= it->first.second;
+          C.size_of.erase(it->second);
+          it = C.idle.erase(it);
+        } else {
+          ++it;
+        }
+    }
+    for (void* q : drop) (void)hipFree(q);
+    (void)hipGetLastError();
+    e = hipMalloc(out, bytes);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> g(C.mu);
+  C.size_of[*out] = bytes;
+  return hipSuccess;
+}
+// (the caller has waited for the device: nothing in flight reads the block any more)
+void block_free(int dev, void* p) {
+  if (!p) return;
+  BlockCache& C = block_cache();
+  {
+    std::lock_guard<std::mutex> g(C.mu);
+    auto it = C.size_of.find(p);
+    if (it != C.size_of.end() && C.idle_bytes + it->second <= block_cache_limit()) {
+      C.idle.insert({{dev, it->second}, p});
+      C.idle_bytes += it->second;
+      return;
+    }
+    if (it != C.size_of.end()) C.size_of.erase(it);
+  }
+  (void)hipFree(p);
+}
+void block_trim(int dev) {
+  BlockCache& C = block_cache();
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> g(C.mu);
+    for (auto it = C.idle.begin(); it != C.idle.end();)
+      if (it->first.first == dev) {
+        drop.push_back(it->second);
+        C.idle_bytes -= it->first.second;
+        C.size_of.erase(it->second);
+        it = C.idle.erase(it);
+      } else {
+        ++it;
+      }
+  }
+  for (void* q : drop) (void)hipFree(q);
+}
+
 }  // namespace
 
 struct gf_index {
@@ -117,13 +210,16 @@ struct gf_index {
 
   void free_lanes();
   ~gf_index() {
-    if (d_slots) (void)hipFree(d_slots);
-    if (d_dupes) (void)hipFree(d_dupes);
-    if (d_lin_base) (void)hipFree(d_lin_base);
-    if (d_lin_hi) (void)hipFree(d_lin_hi);
-    if (d_gene_len) (void)hipFree(d_gene_len);
-    if (d_gdu) (void)hipFree(d_gdu);
-    if (d_bloom) (void)hipFree(d_bloom);
+    // hipFree used to wait for the device; the blocks go back to the cache instead, so wait here: work queued
+    // by the asynchronous entry points may still read the table
+    (void)hipDeviceSynchronize();
+    block_free(device, d_slots);
+    block_free(device, d_dupes);
+    block_free(device, d_lin_base);
+    block_free(device, d_lin_hi);
+    block_free(device, d_gene_len);
+    block_free(device, d_gdu);
+    block_free(device, d_bloom);
     if (d_gene_rev) (void)hipFree(d_gene_rev);
     free_lanes();
     if (have_events) {
@@ -387,22 +483,22 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   const uint32_t nbuckets = (uint32_t)nb64;
   const uint64_t nslots = (uint64_t)nbuckets * GF_SLOTS_PER_BUCKET;
 
-  DevBuf<uint8_t> d_cat;
+  struct CatBlock { int dev; uint8_t* p = nullptr; ~CatBlock() { if (p) { (void)hipDeviceSynchronize(); block_free(dev, p); } } } d_cat{dev};
   DevBuf<uint32_t> d_goff;
   DevBuf<unsigned long long> d_stats;
-  GF_HIP(d_cat.alloc(cat_bytes));
+  GF_HIP(block_alloc(dev, (void**)&d_cat.p, cat_bytes));
   GF_HIP(d_goff.alloc((size_t)n_genes + 1));
   GF_HIP(d_stats.alloc(8));
   // both strands of the genes in site-code space + per-site uniqueness bits (diagonal
   // verification of the mapping kernel); padded so that a 256-base read hanging over
   // either end of the space stays inside the arrays
   const size_t gd_words = (size_t)(lin_cursor / 16) + 64;
-  GF_HIP(hipMalloc((void**)&ix->d_gdu, 2 * gd_words * sizeof(uint32_t)));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_gdu, 2 * gd_words * sizeof(uint32_t)));
   GF_HIP(hipMemset(ix->d_gdu, 0, 2 * gd_words * sizeof(uint32_t)));
-  GF_HIP(hipMalloc((void**)&ix->d_slots, nslots * sizeof(uint64_t)));
-  GF_HIP(hipMalloc((void**)&ix->d_lin_base, lin_base.size() * sizeof(uint32_t)));
-  GF_HIP(hipMalloc((void**)&ix->d_lin_hi, lin_hi.size() * sizeof(uint32_t)));
-  GF_HIP(hipMalloc((void**)&ix->d_gene_len, glen.size() * sizeof(uint32_t)));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_slots, nslots * sizeof(uint64_t)));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_lin_base, lin_base.size() * sizeof(uint32_t)));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_lin_hi, lin_hi.size() * sizeof(uint32_t)));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_gene_len, glen.size() * sizeof(uint32_t)));
   GF_HIP(hipMemset(ix->d_slots, 0, nslots * sizeof(uint64_t)));
   GF_HIP(hipMemset(d_stats.p, 0, 8 * sizeof(unsigned long long)));
   GF_HIP(hipMemcpy(d_cat.p, cat.data(), cat_bytes, hipMemcpyHostToDevice));
@@ -437,7 +533,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   const uint64_t n_dupe_sites = stats[5];
   if (n_dupe_sites > (uint64_t)GF_DUPE_START_MASK)
     return fail(GF_ERR_CAPACITY, "too many duplicated sites for the 26-bit duplicate index");
-  GF_HIP(hipMalloc((void**)&ix->d_dupes, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t)));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_dupes, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t)));
   GF_HIP(hipMemset(ix->d_dupes, 0xFF, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t)));
   // presence filter over canonical 14-mers, filled by the FILL pass.  Indexes up to ~14 M keys: <= GF_BLOOM_KIB
   // (default 3 MiB) so that it lives in every XCD's L2, and seed+verify runs the filter pass for reads
@@ -475,7 +571,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     }
     if (words) {
       bloom_words = (uint32_t)words;
-      GF_HIP(hipMalloc((void**)&ix->d_bloom, (size_t)bloom_words * sizeof(uint32_t)));
+      GF_HIP(block_alloc(dev, (void**)&ix->d_bloom, (size_t)bloom_words * sizeof(uint32_t)));
       GF_HIP(hipMemset(ix->d_bloom, 0, (size_t)bloom_words * sizeof(uint32_t)));
     }
   }
@@ -1860,6 +1956,7 @@ int gf_index_trim(gf_index* idx) {
         kv.second.bytes = 0;
       }
   }
+  block_trim(idx->device);  // device blocks of freed indexes
   return GF_OK;
 }
 

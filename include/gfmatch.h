@@ -110,7 +110,10 @@ int gf_index_info_get(const gf_index* idx, gf_index_info* out);
  * largest span mapped on that stream, at most 2^30 reads per span; owned by the process so that it
  * survives the index rebuilds of multi-CSV mode) and, per index, the arenas of the host-buffer entry
  * points.  gf_index_trim waits for the work queued on those streams and frees them all for the
- * index's device (they grow again on demand); gf_index_free frees what the index owns. */
+ * index's device (they grow again on demand).  gf_index_free waits for the device and hands the index's
+ * device blocks to a cache that the next gf_index_build on that device draws from (multi-CSV mode rebuilds the
+ * index per CSV); at most GF_INDEX_CACHE_MIB MiB (environment, default 2048, 0 = none) stay cached, and
+ * gf_index_trim frees those too. */
 int gf_index_trim(gf_index* idx);
 
 /* Test hook: one of the index's derived device arrays, copied to the host as it is.  Returns its size in

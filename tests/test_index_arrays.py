@@ -147,3 +147,38 @@ def test_export_rejects_unknown_array(gpu_device):
         assert _lib.lib().gf_index_export(ix._handle(), 7, None, 0) < 0
     finally:
         ix.close()
+
+
+def test_rebuilds_reuse_device_blocks_and_trim_returns_them(gpu_device):
+    """Multi-CSV mode frees and rebuilds the index per CSV (fusion_scan.rs:62-188): the freed index's device
+    blocks are kept for the next build, rebuilt indexes answer like the first build, gf_index_trim gives the
+    blocks back to the device."""
+    import torch
+    from genefuserust_amd import Indexer, _lib
+    rng = np.random.default_rng(7)
+    big = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=1_500_000)) for _ in range(2)]
+    small = _genes(rng)
+    first = None
+    for rep in range(3):       # alternating sizes, like the CSV list
+        for genes in (big, small):
+            ix = Indexer.from_gene_slices(genes)
+            ix.make_index()
+            if genes is small:
+                arrays = [_export(ix, k).copy() for k in (0, 1, 2)]
+                if first is None:
+                    first = arrays
+                else:   # a reused (dirty) block is cleared like a fresh one
+                    assert all((a == b).all() for a, b in zip(first, arrays))
+            table_bytes = ix.info()["table_bytes"]
+            ix.close()
+    ix = Indexer.from_gene_slices([b"ACGTTGCA" * 8])
+    ix.make_index()
+    try:
+        torch.cuda.synchronize()
+        free_a = torch.cuda.mem_get_info(gpu_device)[0]
+        _lib.check(_lib.lib().gf_index_trim(ix._handle()))
+        free_b = torch.cuda.mem_get_info(gpu_device)[0]
+        assert free_b - free_a >= 3_000_000 * 2 * 8 // 4 * 8 // 2, (free_a, free_b)   # at least half of the big table
+        assert (_export(ix, 2) == _export(ix, 2)).all()
+    finally:
+        ix.close()
