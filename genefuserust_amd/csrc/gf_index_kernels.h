@@ -37,12 +37,32 @@ __device__ __forceinline__ uint64_t gf_atomic_load64(uint64_t* p) {
 }
 
 // COUNT pass: claim a slot for `key` (or find it) and bump its occurrence count.
+// A bucket's slots are claimed in order (a slot is taken only by a thread that saw every slot before it
+// occupied), so the occupied slots are a prefix.  The eight slots are read at once — one round trip to the
+// bucket's 64-byte line in place of one per occupied slot — and the slot-by-slot search starts at the first
+// slot that was still empty in that snapshot; keys never change or leave, so a key seen there is there.
 __device__ __forceinline__ void gf_insert_count(uint64_t* slots, uint32_t nbuckets, uint32_t key) {
   uint32_t b = gf_bucket_of(key, nbuckets);
   for (uint32_t guard = 0; guard <= nbuckets; ++guard) {
     uint64_t* bucket = slots + (size_t)b * GF_SLOTS_PER_BUCKET;
-    for (int j = 0; j < GF_SLOTS_PER_BUCKET; ++j) {
-      uint64_t cur = gf_atomic_load64(bucket + j);
+    // (plain loads: a stale line shows an earlier state of the bucket — fewer slots taken, never a wrong key —
+    //  and the CAS below finds out what a slot holds by now)
+    const uint4* q = (const uint4*)bucket;
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const uint32_t lo[8] = {q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.z};
+    const uint32_t hi[8] = {q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.y, q3.w};
+    int hit = -1, first_empty = GF_SLOTS_PER_BUCKET;
+#pragma unroll
+    for (int j = GF_SLOTS_PER_BUCKET - 1; j >= 0; --j) {
+      if ((lo[j] & GF_VAL_LOW) == 0) first_empty = j;
+      else if (hi[j] == key) hit = j;
+    }
+    if (hit >= 0) {
+      atomicAdd((unsigned int*)(bucket + hit), 1u);  // low word = count
+      return;
+    }
+    for (int j = first_empty; j < GF_SLOTS_PER_BUCKET; ++j) {
+      uint64_t cur = j == first_empty ? 0ull : gf_atomic_load64(bucket + j);
       if ((cur & GF_VAL_LOW) == 0) {
         uint64_t want = ((uint64_t)key << 32) | 1ull;
         uint64_t prev = atomicCAS((unsigned long long*)(bucket + j), 0ull, (unsigned long long)want);
@@ -50,7 +70,7 @@ __device__ __forceinline__ void gf_insert_count(uint64_t* slots, uint32_t nbucke
         cur = prev;
       }
       if ((uint32_t)(cur >> 32) == key) {
-        atomicAdd((unsigned int*)(bucket + j), 1u);  // low word = count
+        atomicAdd((unsigned int*)(bucket + j), 1u);
         return;
       }
     }
@@ -59,17 +79,21 @@ __device__ __forceinline__ void gf_insert_count(uint64_t* slots, uint32_t nbucke
   }
 }
 
-// Slot holding `key` (must have been inserted).
+// Slot holding `key` (must have been inserted; the table no longer changes its keys).
 __device__ __forceinline__ uint64_t* gf_find_slot(uint64_t* slots, uint32_t nbuckets, uint32_t key) {
   uint32_t b = gf_bucket_of(key, nbuckets);
   for (uint32_t guard = 0; guard <= nbuckets; ++guard) {
     uint64_t* bucket = slots + (size_t)b * GF_SLOTS_PER_BUCKET;
-    uint64_t first = bucket[0];
-    for (int j = 0; j < GF_SLOTS_PER_BUCKET; ++j) {
-      uint64_t cur = j ? bucket[j] : first;
-      if ((cur & GF_VAL_LOW) != 0 && (uint32_t)(cur >> 32) == key) return bucket + j;
-    }
-    if (!((uint32_t)first & GF_VAL_OVF)) return nullptr;
+    const uint4* q = (const uint4*)bucket;  // the whole 64-byte line, four loads in flight
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const uint32_t lo[8] = {q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.z};
+    const uint32_t hi[8] = {q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.y, q3.w};
+    int hit = -1;
+#pragma unroll
+    for (int j = GF_SLOTS_PER_BUCKET - 1; j >= 0; --j)
+      if ((lo[j] & GF_VAL_LOW) != 0 && hi[j] == key) hit = j;
+    if (hit >= 0) return bucket + hit;
+    if (!(lo[0] & GF_VAL_OVF)) return nullptr;
     b = (b + 1 == nbuckets) ? 0 : b + 1;
   }
   return nullptr;
@@ -275,60 +299,49 @@ __global__ __launch_bounds__(256) void gf_k_index_strands(GfGenes G, const uint3
 }
 
 // stats[0]=n_sites [1]=n_keys [2]=n_unique [3]=n_dupe_keys [4]=n_high [5]=n_dupe_sites
-// [6]=dupes cursor (used by the assign pass)
-__global__ void gf_k_classify_count(const uint64_t* slots, uint64_t nslots,
-                                    unsigned long long* stats) {
-  unsigned long long sites = 0, keys = 0, uniq = 0, dk = 0, high = 0, ds = 0;
-  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots;
-       s += (uint64_t)gridDim.x * blockDim.x) {
-    uint32_t c = (uint32_t)slots[s] & GF_VAL_LOW;
-    if (!c) continue;
-    sites += c;
-    keys += 1;
-    if (c == 1) uniq += 1;
-    else if (c <= GF_DUP_THRESHOLD) { dk += 1; ds += c; }
-    else high += 1;
-  }
-  // one atomic per block and statistic (one per wave serialised ~100 K atomics on six addresses)
-  __shared__ unsigned long long s_part[6][4];
-  unsigned long long v[6] = {sites, keys, uniq, dk, high, ds};
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    unsigned long long x = v[k];
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
-    if ((threadIdx.x & 63) == 0) s_part[k][(threadIdx.x >> 6) & 3] = x;
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    unsigned long long x = 0;
-    for (unsigned int w = 0; w < (blockDim.x + 63) / 64 && w < 4; ++w) x += s_part[threadIdx.x][w];
-    if (x) atomicAdd(stats + threadIdx.x, x);
-  }
-}
-
-// A thread takes one bucket (8 consecutive slots = one 64-byte line), a block 256 buckets per round: the room
-// in dupes[] for the round's 2..5-fold keys is ONE atomic on the shared counter (a block scan hands out the
-// parts).  The first form took one per wavefront: a quarter of a million same-address atomics on a
-// cancer-sized table, most of the kernel's 1.16 ms.
+// [6]=dupes cursor
+// One sweep over the table after the COUNT pass: counts -> unique / dupes(start in dupes[]) / HIGH, and the
+// statistics on the way.  A thread takes one bucket (8 consecutive slots = one 64-byte line), a block 256
+// buckets per round: the room in dupes[] for the round's 2..5-fold keys is ONE atomic on the shared counter (a
+// block scan hands out the parts).  The first form took one per wavefront: a quarter of a million same-address
+// atomics on a cancer-sized table, most of the kernel's 1.16 ms.  The statistics are one atomic per block and
+// number (one per wave serialised ~100 K atomics on six addresses).
 __global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uint64_t nslots, unsigned long long* stats) {
   __shared__ uint32_t s_wave[4];
   __shared__ unsigned long long s_base;
+  __shared__ unsigned long long s_part[6][4];
   const uint64_t nbuckets = nslots / GF_SLOTS_PER_BUCKET;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t rounds = (nbuckets + stride - 1) / stride;  // whole blocks stay in the loop for the barriers
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long sites = 0;
+  uint32_t keys = 0, uniq = 0, dk = 0, high = 0, ds = 0;
   for (uint64_t it = 0; it < rounds; ++it) {
     const uint64_t b = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t val[GF_SLOTS_PER_BUCKET], want[GF_SLOTS_PER_BUCKET];
     uint32_t mine = 0;
     uint64_t* base_slot = slots + b * GF_SLOTS_PER_BUCKET;
+    if (b < nbuckets) {
+      const uint4* q = (const uint4*)base_slot;
+      const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+      val[0] = q0.x; val[1] = q0.z; val[2] = q1.x; val[3] = q1.z;
+      val[4] = q2.x; val[5] = q2.z; val[6] = q3.x; val[7] = q3.z;
+    } else {
+#pragma unroll
+      for (int k = 0; k < GF_SLOTS_PER_BUCKET; ++k) val[k] = 0;
+    }
 #pragma unroll
     for (int k = 0; k < GF_SLOTS_PER_BUCKET; ++k) {
-      val[k] = b < nbuckets ? (uint32_t)base_slot[k] : 0u;
       const uint32_t c = val[k] & GF_VAL_LOW;
       want[k] = (c >= 2 && c <= GF_DUP_THRESHOLD) ? c : 0u;
       mine += want[k];
+      sites += c;
+      keys += c != 0;
+      uniq += c == 1;
+      dk += want[k] != 0;
+      high += c > GF_DUP_THRESHOLD;
     }
+    ds += mine;
     uint32_t incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -355,7 +368,7 @@ __global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uin
         if (c == 1) {
           nv = GF_TYPE_UNIQUE << GF_TYPE_SHIFT;
         } else if (c <= GF_DUP_THRESHOLD) {
-          nv = (GF_TYPE_DUPES << GF_TYPE_SHIFT) | (c << GF_DUPE_COUNT_SHIFT) | start;
+          nv = (GF_TYPE_DUPES << GF_TYPE_SHIFT) | (c << GF_DUPE_COUNT_SHIFT) | (start & GF_DUPE_START_MASK);
           start += c;
         } else {
           nv = GF_TYPE_HIGH << GF_TYPE_SHIFT;
@@ -364,6 +377,19 @@ __global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uin
       }
     }
     __syncthreads();  // s_wave / s_base are rewritten in the next round
+  }
+  unsigned long long v[6] = {sites, keys, uniq, dk, high, ds};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    unsigned long long x = v[k];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+    if (lane == 0) s_part[k][wave] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    unsigned long long x = 0;
+    for (int w = 0; w < 4; ++w) x += s_part[threadIdx.x][w];
+    if (x) atomicAdd(stats + threadIdx.x, x);
   }
 }
 

@@ -526,15 +526,18 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
                        ix->d_slots, nbuckets, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     GF_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(gf_k_classify_count, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
+  // the duplicate lists are sized before their keys are counted: every site could be in one (the block comes
+  // from the cache of freed indexes in multi-CSV mode); the sweep that assigns them counts the keys on its way
+  const uint64_t dupes_cap = std::max<uint64_t>(std::min<uint64_t>(site_bound, (uint64_t)GF_DUPE_START_MASK + 1), 1);
+  GF_HIP(block_alloc(dev, (void**)&ix->d_dupes, dupes_cap * sizeof(uint32_t)));
+  hipLaunchKernelGGL(gf_k_classify_assign, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
   GF_HIP(hipGetLastError());
   GF_HIP(hipMemcpy(stats, d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
-  lap("strands, count pass, statistics");
+  lap("strands, count pass, list assignment + statistics");
   const uint64_t n_dupe_sites = stats[5];
   if (n_dupe_sites > (uint64_t)GF_DUPE_START_MASK)
     return fail(GF_ERR_CAPACITY, "too many duplicated sites for the 26-bit duplicate index");
-  GF_HIP(block_alloc(dev, (void**)&ix->d_dupes, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t)));
-  GF_HIP(hipMemset(ix->d_dupes, 0xFF, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t)));
+  GF_HIP(hipMemsetAsync(ix->d_dupes, 0xFF, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t), 0));
   // presence filter over canonical 14-mers, filled by the FILL pass.  Indexes up to ~14 M keys: <= GF_BLOOM_KIB
   // (default 3 MiB) so that it lives in every XCD's L2, and seed+verify runs the filter pass for reads
   // without a candidate diagonal itself.  Up to ~30 M keys: 2.2 bits per key, up to
@@ -575,9 +578,6 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
       GF_HIP(hipMemset(ix->d_bloom, 0, (size_t)bloom_words * sizeof(uint32_t)));
     }
   }
-  hipLaunchKernelGGL(gf_k_classify_assign, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
-  GF_HIP(hipGetLastError());
-  lap("list assignment");
   if (ntiles > 0) {
     hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_FILL>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
                        ix->d_slots, nbuckets, ix->d_dupes, ix->d_gdu, ix->d_bloom, bloom_words);
@@ -612,7 +612,7 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   I.n_high_keys = (int64_t)stats[4];
   I.n_dupe_sites = (int64_t)stats[5];
   I.n_buckets = nbuckets;
-  I.table_bytes = (int64_t)(nslots * sizeof(uint64_t) + std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t) +
+  I.table_bytes = (int64_t)(nslots * sizeof(uint64_t) + dupes_cap * sizeof(uint32_t) +  // (as allocated)
                             2 * gd_words * sizeof(uint32_t) + (size_t)bloom_words * sizeof(uint32_t));
   I.device = dev;
   *out_index = ix.release();
@@ -1945,12 +1945,14 @@ int gf_index_trim(gf_index* idx) {
       if (L->pinned) { GF_HIP(hipHostFree(L->pinned)); L->pinned = nullptr; L->pinned_bytes = 0; }
     }
   }
+  // Calls queued on the workspaces' streams may still use them: wait for the whole device, not stream by
+  // stream — a stream the caller has destroyed since is still a key here, and must not be touched.
+  GF_HIP(hipDeviceSynchronize());
   for (int k = 1; k >= 0; --k) {  // (lock order: pair pool, then map pool — as gf_scan_pairs_device takes them)
     WsPool& P = ws_pool(k == 1);
     std::lock_guard<std::mutex> lk(P.mu);
     for (auto& kv : P.ws)
       if (kv.first.device == idx->device && kv.second.base) {
-        GF_HIP(hipStreamSynchronize(kv.first.st));  // calls queued on that stream may still use it
         GF_HIP(hipFree(kv.second.base));
         kv.second.base = nullptr;
         kv.second.bytes = 0;
