@@ -368,6 +368,10 @@ struct GfMergeBytes {
   uint8_t a1[5], b1[5], a2[5], b2[5];  // R1 base/quality, R2 base/quality for output bytes lane, lane+64, ..
 };
 
+// WITH_QUALS = false: the bases alone (the pair pipeline maps them and needs a merged read's qualities only for
+// the few reads that end in the hit list: gf_merged_qual).  Qualities decide a base only where the two reads
+// disagree inside the overlap (<= 2 columns of a merged pair), and are fetched there.
+template <bool WITH_QUALS>
 __device__ __forceinline__ void gf_mw_load(GfMergeBytes& g, const uint8_t* __restrict__ s1, const uint8_t* __restrict__ q1,
                                            const uint8_t* __restrict__ s2, const uint8_t* __restrict__ q2, int len1,
                                            int len2, int mlen, int offset, int k0, int lane) {
@@ -376,14 +380,16 @@ __device__ __forceinline__ void gf_mw_load(GfMergeBytes& g, const uint8_t* __res
     const int k = k0 + 64 * u + lane;
     g.a1[u] = g.b1[u] = g.a2[u] = g.b2[u] = 0;
     if (k < mlen) {
-      if (k < len1) { g.a1[u] = s1[k]; g.b1[u] = q1[k]; }
-      if (k >= offset) { g.a2[u] = s2[len2 - 1 - (k - offset)]; g.b2[u] = q2[len2 - 1 - (k - offset)]; }
+      if (k < len1) { g.a1[u] = s1[k]; if (WITH_QUALS) g.b1[u] = q1[k]; }
+      if (k >= offset) { g.a2[u] = s2[len2 - 1 - (k - offset)]; if (WITH_QUALS) g.b2[u] = q2[len2 - 1 - (k - offset)]; }
     }
   }
 }
 
+template <bool WITH_QUALS>
 __device__ __forceinline__ void gf_mw_store(const GfMergeBytes& g, uint8_t* __restrict__ os, uint8_t* __restrict__ oq,
-                                            int len1, int mlen, int offset, int k0, int lane) {
+                                            const uint8_t* __restrict__ q1, const uint8_t* __restrict__ q2, int len1,
+                                            int len2, int mlen, int offset, int k0, int lane) {
   const int olen = len1 - offset;
 #pragma unroll
   for (int u = 0; u < 5; ++u) {
@@ -395,7 +401,9 @@ __device__ __forceinline__ void gf_mw_store(const GfMergeBytes& g, uint8_t* __re
         cq = g.b2[u];
         if (k - offset < olen) {
           if (g.a1[u] != cs) {
-            if (g.b1[u] >= '?' && cq <= '0') { cs = g.a1[u]; cq = g.b1[u]; }
+            const uint8_t b1 = WITH_QUALS ? g.b1[u] : q1[k];
+            const uint8_t b2 = WITH_QUALS ? cq : q2[len2 - 1 - (k - offset)];
+            if (b1 >= '?' && b2 <= '0') { cs = g.a1[u]; cq = b1; }
           } else {
             const uint32_t q = (uint32_t)g.b1[u] + (uint32_t)cq - 33u;  // add the pair's qualities, cap at 'Z'
             cq = q >= (uint32_t)'Z' ? (uint8_t)'Z' : (uint8_t)q;
@@ -403,11 +411,30 @@ __device__ __forceinline__ void gf_mw_store(const GfMergeBytes& g, uint8_t* __re
         }
       }
       os[k] = cs;
-      oq[k] = cq;
+      if (WITH_QUALS) oq[k] = cq;
     }
   }
 }
 
+// Quality k of the merged read of a pair (read.rs:402-428), from the pair's own bytes: what gf_k_merge_write<true>
+// stores at out_quals[k].  Four loads at clamped positions and a selection — no branch, so that a caller's
+// unrolled loop has all its loads in flight at once.
+__device__ __forceinline__ uint8_t gf_merged_qual(const uint8_t* __restrict__ s1, const uint8_t* __restrict__ q1, int len1,
+                                                  const uint8_t* __restrict__ s2, const uint8_t* __restrict__ q2, int len2,
+                                                  int mlen, int k) {
+  const int offset = mlen - len2;
+  const int k1 = k < len1 ? k : len1 - 1;
+  int j = len2 - 1 - (k - offset);
+  j = j < 0 ? 0 : (j > len2 - 1 ? len2 - 1 : j);
+  const uint8_t a1 = s1[k1], b1 = q1[k1], a2 = s2[j], b2 = q2[j];
+  const uint32_t sum = (uint32_t)b1 + (uint32_t)b2 - 33u;
+  const uint8_t same = sum >= (uint32_t)'Z' ? (uint8_t)'Z' : (uint8_t)sum;
+  const uint8_t diff = (b1 >= '?' && b2 <= '0') ? b1 : b2;
+  const uint8_t in_overlap = a1 != gf_complement(a2) ? diff : same;
+  return k < offset ? b1 : (k >= len1 ? b2 : in_overlap);
+}
+
+template <bool WITH_QUALS>
 __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restrict__ l_bases,
                                                         const uint8_t* __restrict__ l_quals,
                                                         const int64_t* __restrict__ l_off,
@@ -451,13 +478,156 @@ __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restric
       const int mmax = mla > mlb ? mla : mlb;
       for (int k0 = 0; k0 < mmax; k0 += 320) {
         GfMergeBytes ga, gb;
-        gf_mw_load(ga, l_bases + s_l[e0], l_quals + s_l[e0], r_bases + s_r[e0], r_quals + s_r[e0], len1a, len2a, mla,
-                   offa, k0, lane);
-        gf_mw_load(gb, l_bases + s_l[ex], l_quals + s_l[ex], r_bases + s_r[ex], r_quals + s_r[ex], len1b, len2b, mlb,
-                   offb, k0, lane);
+        gf_mw_load<WITH_QUALS>(ga, l_bases + s_l[e0], l_quals + s_l[e0], r_bases + s_r[e0], r_quals + s_r[e0], len1a, len2a,
+                               mla, offa, k0, lane);
+        gf_mw_load<WITH_QUALS>(gb, l_bases + s_l[ex], l_quals + s_l[ex], r_bases + s_r[ex], r_quals + s_r[ex], len1b, len2b,
+                               mlb, offb, k0, lane);
         __builtin_amdgcn_sched_barrier(0);  // both pairs' loads before anybody's stores
-        gf_mw_store(ga, out_bases + s_dst[e0], out_quals + s_dst[e0], len1a, mla, offa, k0, lane);
-        gf_mw_store(gb, out_bases + s_dst[ex], out_quals + s_dst[ex], len1b, mlb, offb, k0, lane);
+        gf_mw_store<WITH_QUALS>(ga, out_bases + s_dst[e0], WITH_QUALS ? out_quals + s_dst[e0] : nullptr, l_quals + s_l[e0],
+                                r_quals + s_r[e0], len1a, len2a, mla, offa, k0, lane);
+        gf_mw_store<WITH_QUALS>(gb, out_bases + s_dst[ex], WITH_QUALS ? out_quals + s_dst[ex] : nullptr, l_quals + s_l[ex],
+                                r_quals + s_r[ex], len1b, len2b, mlb, offb, k0, lane);
+      }
+    }
+  }
+}
+
+// ---- K_merge_write_bases: the merged reads' bases alone, eight bytes per lane ----
+// The pair pipeline (gf_scan_pairs_device) maps the merged reads and needs their qualities only for the few
+// that are searched again or end in the hit list (gf_merged_qual).  Same block structure as gf_k_merge_write —
+// the merged pairs of 256 are listed in LDS, a wavefront takes two of them at a time — but a lane produces eight
+// consecutive bytes of the merged read: a piece of R1 as it is, a piece of rc(R2) from eight bytes of R2 turned
+// round and complemented four at a time, a piece of the overlap from both (equal: done; different: the
+// qualities of the differing columns decide, read.rs:402-428).  Only the pieces that straddle the start of
+// rc(R2), the end of R1 or the end of the read go byte by byte.  A 300-base read is one round trip of 38 lanes
+// where the byte-per-lane form makes five.
+struct __attribute__((packed, aligned(1))) GfBytes8 { uint32_t v[2]; };
+
+// reverse complement of four bases in a dword (sequence.rs:22-60: anything outside ACGTacgt -> 'N', upper case)
+__device__ __forceinline__ uint32_t gf_rc4(uint32_t w) {
+  const uint32_t y = (w >> 1) & 0x03030303u;
+  const uint32_t d = (w & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, y);  // 0 where the byte is ACGTacgt
+  uint32_t c = __builtin_amdgcn_perm(0u, 0x43414754u, y);                              // A->T C->G T->A G->C
+  if (d) {
+    const uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;
+    const uint32_t m = nz * 0xFFu;
+    c = (c & ~m) | (0x4E4E4E4Eu & m);
+  }
+  return __builtin_bswap32(c);
+}
+
+// byte kk of the merged read
+__device__ __forceinline__ uint8_t gf_merged_base(const uint8_t* __restrict__ s1, const uint8_t* __restrict__ q1, int len1,
+                                                  const uint8_t* __restrict__ s2, const uint8_t* __restrict__ q2, int len2,
+                                                  int offset, int kk) {
+  if (kk < offset) return s1[kk];
+  const int j = len2 - 1 - (kk - offset);
+  uint8_t cs = gf_complement(s2[j]);
+  if (kk < len1) {
+    const uint8_t b1 = s1[kk];
+    if (b1 != cs && q1[kk] >= '?' && q2[j] <= '0') cs = b1;
+  }
+  return cs;
+}
+
+// Bytes k .. k+7 of the merged read, no branches on where the piece lies: eight bytes of R1 at k and the eight
+// bytes of R2 that rc(R2) takes its bytes k-offset .. k-offset+7 from are fetched whatever the piece covers
+// (reading up to 7 bytes past either read's end: the 16-byte over-read every device buffer of the ABI allows; a
+// piece that runs past the end of the merged read would start BEFORE R2 — it loads from R2's first byte and
+// shifts), and every output byte picks its source by position.
+__device__ __forceinline__ void gf_mwb_piece(const uint8_t* __restrict__ s1, const uint8_t* __restrict__ q1, int len1,
+                                             const uint8_t* __restrict__ s2, const uint8_t* __restrict__ q2, int len2,
+                                             int mlen, int offset, int k, uint8_t* __restrict__ os) {
+  if (k >= mlen) return;
+  const GfBytes8 a = *(const GfBytes8*)(s1 + (k < len1 ? k : 0));  // (not used at all when k >= len1)
+  int jl = len2 - 1 - (k + 7 - offset);                            // R2 index of output byte k+7
+  const int under = jl < 0 ? -jl : 0;                              // > 0 only in the read's last piece
+  if (k + 8 <= offset) jl = 0;  // a piece of R1 alone: rc(R2) is not looked at (and jl would lie past R2's end)
+  const GfBytes8 t = *(const GfBytes8*)(s2 + (jl < 0 ? 0 : jl));
+  uint64_t t64 = (uint64_t)t.v[0] | ((uint64_t)t.v[1] << 32);
+  t64 <<= 8 * under;
+  uint32_t o0 = gf_rc4((uint32_t)(t64 >> 32)), o1 = gf_rc4((uint32_t)t64);  // rc(R2) bytes for k..k+3, k+4..k+7
+  // bytes below `offset` come from R1
+  const int n1 = offset - k;  // number of leading bytes that are R1's
+  if (n1 > 0) {
+    const uint32_t m0 = n1 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * n1)) - 1u);
+    const uint32_t m1 = n1 >= 8 ? 0xFFFFFFFFu : (n1 <= 4 ? 0u : ((1u << (8 * (n1 - 4))) - 1u));
+    o0 = (a.v[0] & m0) | (o0 & ~m0);
+    o1 = (a.v[1] & m1) | (o1 & ~m1);
+  }
+  // inside the overlap (offset <= pos < len1) a column where the reads disagree is R1's when R1 is sure and R2 is not
+  if (k < len1 && k + 8 > offset) {
+    uint32_t x0 = a.v[0] ^ o0, x1 = a.v[1] ^ o1;
+    if (x0 | x1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pos = k + i;
+        const uint32_t xb = ((i < 4 ? x0 : x1) >> (8 * (i & 3))) & 0xFFu;
+        if (xb && pos >= offset && pos < len1 && pos < mlen) {
+          if (q1[pos] >= '?' && q2[len2 - 1 - (pos - offset)] <= '0') {
+            const uint32_t b1 = ((i < 4 ? a.v[0] : a.v[1]) >> (8 * (i & 3))) & 0xFFu;
+            if (i < 4) o0 = (o0 & ~(0xFFu << (8 * (i & 3)))) | (b1 << (8 * (i & 3)));
+            else o1 = (o1 & ~(0xFFu << (8 * (i & 3)))) | (b1 << (8 * (i & 3)));
+          }
+        }
+      }
+    }
+  }
+  if (k + 8 <= mlen) {
+    GfBytes8 o;
+    o.v[0] = o0;
+    o.v[1] = o1;
+    *(GfBytes8*)(os + k) = o;
+  } else {
+    const uint64_t o64 = (uint64_t)o0 | ((uint64_t)o1 << 32);
+    for (int i = 0; k + i < mlen; ++i) os[k + i] = (uint8_t)(o64 >> (8 * i));
+  }
+}
+
+__global__ __launch_bounds__(256) void gf_k_merge_write_bases(const uint8_t* __restrict__ l_bases,
+                                                              const uint8_t* __restrict__ l_quals,
+                                                              const int64_t* __restrict__ l_off,
+                                                              const uint8_t* __restrict__ r_bases,
+                                                              const uint8_t* __restrict__ r_quals,
+                                                              const int64_t* __restrict__ r_off, int64_t n,
+                                                              const int32_t* __restrict__ in_len,
+                                                              const int64_t* __restrict__ out_pos,
+                                                              uint8_t* __restrict__ out_bases) {
+  __shared__ unsigned int s_cnt;
+  __shared__ int64_t s_l[256], s_r[256], s_dst[256];
+  __shared__ int s_len1[256], s_len2[256], s_mlen[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t p0 = base + threadIdx.x;
+    const int ml = p0 < n ? in_len[p0] : 0;
+    const bool merged = ml > 0;
+    const unsigned int slot = gf_wave_append_lds(merged, &s_cnt);
+    if (merged) {
+      const int64_t lo = l_off[p0], ro = r_off[p0];
+      s_l[slot] = lo;
+      s_r[slot] = ro;
+      s_len1[slot] = (int)(l_off[p0 + 1] - lo);
+      s_len2[slot] = (int)(r_off[p0 + 1] - ro);
+      s_mlen[slot] = ml;
+      s_dst[slot] = out_pos[p0];
+    }
+    __syncthreads();
+    const unsigned int cnt = s_cnt;
+    for (unsigned int e0 = 2 * wave; e0 < cnt; e0 += 8) {
+      const unsigned int e1 = e0 + 1;
+      const bool two = e1 < cnt;
+      const unsigned int ex = two ? e1 : e0;
+      const int len1a = s_len1[e0], len2a = s_len2[e0], mla = s_mlen[e0];
+      const int len1b = s_len1[ex], len2b = s_len2[ex], mlb = two ? s_mlen[ex] : 0;
+      const int mmax = mla > mlb ? mla : mlb;
+      for (int k0 = 0; k0 < mmax; k0 += 512) {
+        gf_mwb_piece(l_bases + s_l[e0], l_quals + s_l[e0], len1a, r_bases + s_r[e0], r_quals + s_r[e0], len2a, mla,
+                     mla - len2a, k0 + 8 * lane, out_bases + s_dst[e0]);
+        gf_mwb_piece(l_bases + s_l[ex], l_quals + s_l[ex], len1b, r_bases + s_r[ex], r_quals + s_r[ex], len2b, mlb,
+                     mlb - len2b, k0 + 8 * lane, out_bases + s_dst[ex]);
       }
     }
   }

@@ -20,9 +20,11 @@
 
 #include "../../include/gfmatch.h"
 #include "gf_compact_kernels.h"
+#include "gf_merge_kernels.h"
 
 #define GF_PTILE 256  // pairs per tile: one per thread, so that a wavefront reads and writes consecutive pairs
 #define GF_PPER (GF_PTILE / GF_CTHREADS)
+static_assert(GF_PTILE == GF_CTHREADS, "the pair kernels take one pair per thread");
 
 #define GF_PS_NONE 0u
 #define GF_PS_FWD 1u    // two segments in the required direction: a match on the read as it is
@@ -31,7 +33,7 @@
 struct GfPairIn {
   const uint8_t *l_bases, *l_quals, *r_bases, *r_quals;
   const int64_t *l_off, *r_off;
-  const uint8_t *m_bases, *m_quals;  // merged reads, back to back
+  const uint8_t* m_bases;            // merged reads, back to back (their qualities: gf_pair_qual)
   const int64_t* m_off;              // int64[n+1]: an empty slot for a pair that did not merge
   const int32_t* m_len;              // 0 = not merged
   const int32_t* m_diff;
@@ -65,13 +67,68 @@ __device__ __forceinline__ void gf_pair_candidate(const GfPairIn& P, int64_t p, 
   if (s == 0) {
     const int64_t o = P.m_off[p];
     const int64_t j = P.m_len[p] > 0 ? (int64_t)P.m_rank[p] : 0;   // (cM / mM are indexed by merged read, not by pair)
-    bases = P.m_bases + o; quals = P.m_quals + o; len = P.m_len[p]; cnt = P.m_len[p] > 0 ? P.cM[j] : (uint8_t)0; m = P.mM + 2 * j;
+    bases = P.m_bases + o; quals = nullptr; len = P.m_len[p]; cnt = P.m_len[p] > 0 ? P.cM[j] : (uint8_t)0; m = P.mM + 2 * j;
   } else if (s == 1) {
     const int64_t o = P.l_off[p];
     bases = P.l_bases + o; quals = P.l_quals + o; len = (int32_t)(P.l_off[p + 1] - o); cnt = P.c1[p]; m = P.m1 + 2 * p;
   } else {
     const int64_t o = P.r_off[p];
     bases = P.r_bases + o; quals = P.r_quals + o; len = (int32_t)(P.r_off[p + 1] - o); cnt = P.c2[p]; m = P.m2 + 2 * p;
+  }
+}
+
+// The qualities of candidate s of pair p.  A merged read's qualities are not stored: the pipeline needs them for
+// the reads that are searched again as reverse complements or end in the hit list — a few per thousand — and
+// they follow from the pair's own bytes (read.rs:402-428).
+struct GfPairQual {
+  const uint8_t *q, *s1, *q1, *s2, *q2;
+  int len1, len2, mlen;
+  __device__ __forceinline__ uint8_t merged_at(int k) const { return gf_merged_qual(s1, q1, len1, s2, q2, len2, mlen, k); }
+};
+__device__ __forceinline__ GfPairQual gf_pair_qual(const GfPairIn& P, int64_t p, int s, const uint8_t* quals) {
+  GfPairQual Q;
+  Q.q = quals;
+  Q.s1 = Q.q1 = Q.s2 = Q.q2 = nullptr;
+  Q.len1 = Q.len2 = Q.mlen = 0;
+  if (s == 0 && !quals) {
+    const int64_t lo = P.l_off[p], ro = P.r_off[p];
+    Q.s1 = P.l_bases + lo; Q.q1 = P.l_quals + lo; Q.len1 = (int)(P.l_off[p + 1] - lo);
+    Q.s2 = P.r_bases + ro; Q.q2 = P.r_quals + ro; Q.len2 = (int)(P.r_off[p + 1] - ro);
+    Q.mlen = P.m_len[p];
+  }
+  return Q;
+}
+
+// The reads that the lanes in `mask` have to write, one after the other, every read by all 64 lanes of the
+// wavefront (lane j: bytes j, j + 64, ..).  Hits and retries are a few per thousand pairs: a lane that copied
+// its own read byte by byte was alone in its wavefront with one round trip per byte, and the kernel took as
+// long as its longest read had bytes.  revcomp: the read's reverse complement (its qualities reversed).
+__device__ __forceinline__ void gf_wave_write_reads(uint64_t mask, const uint8_t* b, const GfPairQual& Q, int len,
+                                                    long long out, uint8_t* __restrict__ ob, uint8_t* __restrict__ oq,
+                                                    bool revcomp) {
+  const int lane = threadIdx.x & 63;
+  while (mask) {
+    const int l = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    const uint8_t* bb = (const uint8_t*)__shfl((unsigned long long)b, l);
+    GfPairQual R;
+    R.q = (const uint8_t*)__shfl((unsigned long long)Q.q, l);
+    R.s1 = (const uint8_t*)__shfl((unsigned long long)Q.s1, l);
+    R.q1 = (const uint8_t*)__shfl((unsigned long long)Q.q1, l);
+    R.s2 = (const uint8_t*)__shfl((unsigned long long)Q.s2, l);
+    R.q2 = (const uint8_t*)__shfl((unsigned long long)Q.q2, l);
+    R.len1 = __shfl(Q.len1, l);
+    R.len2 = __shfl(Q.len2, l);
+    R.mlen = __shfl(Q.mlen, l);
+    const int ln = __shfl(len, l);
+    const long long o = __shfl(out, l);
+#pragma unroll 1
+    for (int j = lane; j < ln; j += 64) {
+      const int src = revcomp ? ln - 1 - j : j;
+      const uint8_t base = bb[src];
+      ob[o + j] = revcomp ? gf_complement(base) : base;
+      oq[o + j] = R.q ? R.q[src] : R.merged_at(src);
+    }
   }
 }
 
@@ -238,26 +295,27 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_retry_write(
   }
   int ea, ta; long long eb, tb;
   gf_block_scan2(rc, rb, s_a, s_b, ea, eb, ta, tb);
-  if (!rc) return;
+  if (__ballot(rc != 0) == 0) return;  // (whole wavefronts: the reads are written by all 64 lanes)
   int64_t k_out = tile_off_rc[blockIdx.x] + ea;
   int64_t b_out = tile_off_rb[blockIdx.x] + eb;
-  for (int k = 0; k < GF_PPER; ++k) {
-    const int64_t p = p0 + k;
-    if (p >= n) break;
+  const int64_t p = p0;  // GF_PPER == 1
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (st[3 * p + s] != GF_PS_RETRY) continue;
-      const uint8_t* b; const uint8_t* q; int32_t len; uint8_t cnt; const gf_seqmatch* m;
+  for (int s = 0; s < 3; ++s) {
+    const bool mine = p < n && st[3 * p + s] == GF_PS_RETRY;
+    const uint8_t* b = nullptr; const uint8_t* q = nullptr; int32_t len = 0; uint8_t cnt; const gf_seqmatch* m;
+    bool fits = false;
+    GfPairQual Q = gf_pair_qual(P, 0, 1, nullptr);
+    if (mine) {
       gf_pair_candidate(P, p, s, b, q, len, cnt, m);
-      const bool fits = k_out < cap_reads && b_out + len <= cap_bytes;
+      fits = k_out < cap_reads && b_out + len <= cap_bytes;
       slot_of[3 * p + s] = fits ? (int32_t)k_out : -1;
       if (fits) {
         r_off[k_out] = b_out;
-        for (int j = 0; j < len; ++j) {
-          r_bases[b_out + j] = gf_complement_base(b[len - 1 - j]);
-          r_quals[b_out + j] = q[len - 1 - j];
-        }
+        Q = gf_pair_qual(P, p, s, q);
       }
+    }
+    gf_wave_write_reads(__ballot(fits), b, Q, len, (long long)b_out, r_bases, r_quals, true);
+    if (mine) {
       k_out += 1;
       b_out += len;
     }
@@ -359,18 +417,18 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_final_write(
   }
   int ea, ta; long long eb, tb;
   gf_block_scan2(hc, hb, s_a, s_b, ea, eb, ta, tb);
-  if (!hc) return;
+  if (__ballot(hc != 0) == 0) return;  // (whole wavefronts: the reads are written by all 64 lanes)
   int64_t k_out = tile_off_hc[blockIdx.x] + ea;
   int64_t b_out = tile_off_hb[blockIdx.x] + eb;
-  for (int k = 0; k < GF_PPER; ++k) {
-    const int64_t p = p0 + k;
-    if (p >= n) break;
+  const int64_t p = p0;  // GF_PPER == 1
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (st[3 * p + s] == GF_PS_NONE) continue;
-      int slot;
-      if (!gf_pair_final(P, p, s, st, slot_of, cR, mR, slot)) continue;
-      const uint8_t* b; const uint8_t* q; int32_t len; uint8_t cnt; const gf_seqmatch* m;
+  for (int s = 0; s < 3; ++s) {
+    int slot = -1;
+    const bool mine = p < n && st[3 * p + s] != GF_PS_NONE && gf_pair_final(P, p, s, st, slot_of, cR, mR, slot);
+    const uint8_t* b = nullptr; const uint8_t* q = nullptr; int32_t len = 0; uint8_t cnt; const gf_seqmatch* m;
+    bool bytes_fit = false;
+    GfPairQual Q = gf_pair_qual(P, 0, 1, nullptr);
+    if (mine) {
       gf_pair_candidate(P, p, s, b, q, len, cnt, m);
       if (slot >= 0) {  // the match is on the reverse complement: its bases, its mapping
         b = r_bases + r_off[slot];
@@ -391,11 +449,11 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_final_write(
         h.m[1] = m[1];
         hits[k_out] = h;
       }
-      if (b_out + len <= bytes_cap)
-        for (int j = 0; j < len; ++j) {
-          out_bases[b_out + j] = b[j];
-          out_quals[b_out + j] = q[j];
-        }
+      bytes_fit = b_out + len <= bytes_cap;
+      if (bytes_fit) Q = gf_pair_qual(P, p, s, q);  // (q: the retry batch's for a reverse complement)
+    }
+    gf_wave_write_reads(__ballot(bytes_fit), b, Q, len, (long long)b_out, out_bases, out_quals, false);
+    if (mine) {
       k_out += 1;
       b_out += len;
     }

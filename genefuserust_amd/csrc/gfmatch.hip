@@ -1477,14 +1477,20 @@ int gf_fast_merge_write_device(const gf_index* idx, const void* d_l_bases, const
   if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
   if (n == 0) return GF_OK;
   if (!d_l_bases || !d_l_quals || !d_l_offsets || !d_r_bases || !d_r_quals || !d_r_offsets || !d_len ||
-      !d_out_pos || !d_out_bases || !d_out_quals)
+      !d_out_pos || !d_out_bases)
     return fail(GF_ERR_ARG, "null device pointer");
   DeviceGuard guard(idx->device);
   const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 32);
-  hipLaunchKernelGGL(gf_k_merge_write, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_l_bases,
-                     (const uint8_t*)d_l_quals, (const int64_t*)d_l_offsets, (const uint8_t*)d_r_bases,
-                     (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int32_t*)d_len,
-                     (const int64_t*)d_out_pos, (uint8_t*)d_out_bases, (uint8_t*)d_out_quals);
+  if (d_out_quals)
+    hipLaunchKernelGGL(gf_k_merge_write<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_l_bases,
+                       (const uint8_t*)d_l_quals, (const int64_t*)d_l_offsets, (const uint8_t*)d_r_bases,
+                       (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int32_t*)d_len,
+                       (const int64_t*)d_out_pos, (uint8_t*)d_out_bases, (uint8_t*)d_out_quals);
+  else  // the bases alone (gf_scan_pairs_device)
+    hipLaunchKernelGGL(gf_k_merge_write_bases, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_l_bases,
+                       (const uint8_t*)d_l_quals, (const int64_t*)d_l_offsets, (const uint8_t*)d_r_bases,
+                       (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int32_t*)d_len,
+                       (const int64_t*)d_out_pos, (uint8_t*)d_out_bases);
   GF_HIP(hipGetLastError());
   return GF_OK;
 }
@@ -1657,7 +1663,7 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   (void)al;
   const size_t o_mlen = cv.take((size_t)n * 4), o_mdiff = cv.take((size_t)n * 4), o_moff = cv.take(((size_t)n + 1) * 8);
   const size_t o_mrank = cv.take((size_t)n * 4), o_coff = cv.take(((size_t)n + 1) * 8);
-  const size_t o_mb = cv.take((size_t)(l_bytes + r_bytes) + 64), o_mq = cv.take((size_t)(l_bytes + r_bytes) + 64);
+  const size_t o_mb = cv.take((size_t)(l_bytes + r_bytes) + 64);
   const size_t o_cM = cv.take((size_t)n), o_c1 = cv.take((size_t)n), o_c2 = cv.take((size_t)n);
   const size_t o_mM = cv.take((size_t)n * 32), o_m1 = cv.take((size_t)n * 32), o_m2 = cv.take((size_t)n * 32);
   const size_t o_st = cv.take((size_t)n * 3), o_slot = cv.take((size_t)n * 3 * 4);
@@ -1675,7 +1681,7 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   uint8_t* wp = (uint8_t*)base;
   int32_t* m_len = (int32_t*)(wp + o_mlen); int32_t* m_diff = (int32_t*)(wp + o_mdiff); int64_t* m_off = (int64_t*)(wp + o_moff);
   int32_t* m_rank = (int32_t*)(wp + o_mrank); int64_t* c_off = (int64_t*)(wp + o_coff);
-  uint8_t* mb = wp + o_mb; uint8_t* mq = wp + o_mq;
+  uint8_t* mb = wp + o_mb;
   uint8_t *cM = wp + o_cM, *c1 = wp + o_c1, *c2 = wp + o_c2;
   gf_seqmatch *mM = (gf_seqmatch*)(wp + o_mM), *m1 = (gf_seqmatch*)(wp + o_m1), *m2 = (gf_seqmatch*)(wp + o_m2);
   uint8_t* stt = wp + o_st; int32_t* slot_of = (int32_t*)(wp + o_slot);
@@ -1702,7 +1708,7 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
                      (const int64_t*)(scal + 5), (const int64_t*)(scal + 0), n, c_off);
   GF_HIP(hipGetLastError());
   rc = gf_fast_merge_write_device(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, m_len, m_off,
-                                  mb, mq, stream);
+                                  mb, nullptr, stream);
   if (rc != GF_OK) return rc;
   // 2. the merged reads; R1 and R2 of the pairs that did not merge (in place, the others skipped)
   rc = map_reads_device_impl(idx, mb, c_off, n, (int32_t)std::max<int64_t>(merged_max, 1), cM, mM, stream, nullptr);
@@ -1715,7 +1721,7 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   GfPairIn P;
   P.l_bases = (const uint8_t*)d_l_bases; P.l_quals = (const uint8_t*)d_l_quals; P.l_off = (const int64_t*)d_l_offsets;
   P.r_bases = (const uint8_t*)d_r_bases; P.r_quals = (const uint8_t*)d_r_quals; P.r_off = (const int64_t*)d_r_offsets;
-  P.m_bases = mb; P.m_quals = mq; P.m_off = m_off; P.m_len = m_len; P.m_diff = m_diff; P.m_rank = m_rank;
+  P.m_bases = mb; P.m_off = m_off; P.m_len = m_len; P.m_diff = m_diff; P.m_rank = m_rank;
   P.cM = cM; P.c1 = c1; P.c2 = c2; P.mM = mM; P.m1 = m1; P.m2 = m2;
   P.gene_reversed = idx->d_gene_rev; P.n_genes = idx->table.n_genes;
   hipLaunchKernelGGL(gf_k_pair_classify, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, stt, tcA, tcB);

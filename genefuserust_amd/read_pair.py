@@ -55,11 +55,12 @@ def pack_reads(seqs: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
 
 
 def fast_merge_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_quals, r_off, max_read_len: int,
-                      stream=None):
+                      stream=None, with_quals: bool = True):
     """Merge a batch of pairs resident in HBM.  Returns (bases, quals, offsets, diff): the
     merged reads packed back to back in pair order — offsets int64[n+1], a pair that does not
     merge has an empty slot — in the layout ``Indexer.map_reads_device`` takes, plus diff int32[n].
-    gf_fast_merge_find_device, one prefix sum, gf_fast_merge_write_device."""
+    gf_fast_merge_find_device, one prefix sum, gf_fast_merge_write_device.  ``with_quals=False``: the bases
+    alone (quals is None) — the form gf_scan_pairs_device uses, a kernel of its own."""
     import torch
     n = l_off.numel() - 1
     dev = l_bases.device
@@ -78,10 +79,10 @@ def fast_merge_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_qual
         torch.cumsum(out_len[:n], 0, out=offsets[1:])
     total = int(offsets[-1].item()) if n else 0
     bases = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
-    quals = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+    quals = torch.empty(max(total, 1), dtype=torch.uint8, device=dev) if with_quals else None
     _lib.check(L.gf_fast_merge_write_device(h, *args, out_len.data_ptr(), offsets.data_ptr(), bases.data_ptr(),
-                                            quals.data_ptr(), st))
-    return bases[:total], quals[:total], offsets, out_diff[:n]
+                                            quals.data_ptr() if with_quals else None, st))
+    return bases[:total], (quals[:total] if with_quals else None), offsets, out_diff[:n]
 
 
 def fast_merge_batch(indexer: Indexer, pairs: Sequence[SequenceReadPair]) -> List[Optional[MergedRead]]:

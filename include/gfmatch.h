@@ -271,7 +271,8 @@ int64_t gf_edit_distance(const char* a, int64_t alen, const char* b, int64_t ble
  * gf_fast_merge_write_device: writes merged read p (d_len[p] > 0, as produced by _find) at
  *   d_out_pos[p] (int64[n], chosen by the caller — typically the prefix sum of d_len, which
  *   packs the merged reads back to back in the layout gf_map_reads_device takes) of
- *   d_out_bases / d_out_quals.
+ *   d_out_bases / d_out_quals.  d_out_quals may be NULL: the bases alone (qualities decide a base only
+ *   where the reads disagree inside the overlap and are fetched there; half the traffic).
  * gf_fast_merge_device: both steps, for callers whose d_out_pos does not depend on the
  *   lengths (e.g. one slot of len1+len2 bytes per pair). */
 int gf_fast_merge_find_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,

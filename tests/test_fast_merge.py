@@ -134,6 +134,10 @@ def _device_merge(ix, pairs, max_read_len):
     torch.cuda.synchronize()
     b, q, o, d = bases.cpu().numpy().tobytes(), quals.cpu().numpy().tobytes(), off.cpu().numpy(), diff.cpu().numpy()
     got = [(b[o[i]:o[i + 1]], q[o[i]:o[i + 1]], int(d[i])) if o[i + 1] > o[i] else None for i in range(len(pairs))]
+    # the bases-only writer (eight bytes per lane; what the pair pipeline runs) lays down the same bases
+    b2, q2, o2, _ = fast_merge_device(ix, *t, max_read_len, with_quals=False)
+    torch.cuda.synchronize()
+    assert q2 is None and (o2.cpu().numpy() == o).all() and b2.cpu().numpy().tobytes() == b
     return got, (bases, off)
 
 
