@@ -252,6 +252,15 @@ static WsPool& ws_pool(bool pair) {
   return pools[pair ? 1 : 0];
 }
 
+// one launch of gf_k_compact_scan: one array, or two of the same length (block b scans array b)
+static void launch_scan(hipStream_t st, int64_t ntiles, const uint32_t* c0, int64_t* o0, int64_t* t0,
+                        const uint32_t* c1 = nullptr, int64_t* o1 = nullptr, int64_t* t1 = nullptr) {
+  GfScanJobs J;
+  J.j[0] = GfScanJob{c0, o0, t0};
+  J.j[1] = GfScanJob{c1, o1, t1};
+  hipLaunchKernelGGL(gf_k_compact_scan, dim3(c1 ? 2 : 1), dim3(1024), 0, st, J, ntiles);
+}
+
 static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** out, bool pair = false) {
   Workspace& W = ws_pool(pair).ws[WsKey{mix->device, st}];  // caller holds the pool's mutex
   if (W.bytes < need) {
@@ -876,8 +885,7 @@ int gf_compact_hits_device(const gf_index* idx, const void* d_counts, const void
                        (const uint8_t*)d_counts, n, tile_counts);
     GF_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, tile_counts, ntiles, tile_offsets,
-                     (int64_t*)d_n_hits);
+  launch_scan(st, ntiles, tile_counts, tile_offsets, (int64_t*)d_n_hits);
   GF_HIP(hipGetLastError());
   if (ntiles > 0) {
     hipLaunchKernelGGL(gf_k_compact_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st,
@@ -1572,7 +1580,7 @@ int gf_fastq_index_device(const gf_index* idx, const void* d_text, int64_t n_byt
                        tile_counts, masks);
     GF_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, tile_counts, ntiles, tile_offsets, n_lines + 1);
+  launch_scan(st, ntiles, tile_counts, tile_offsets, n_lines + 1);
   GF_HIP(hipGetLastError());
   if (ntiles > 0) {
     hipLaunchKernelGGL(gf_k_fq_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text, n_bytes,
@@ -1608,7 +1616,7 @@ int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_by
   int64_t* total = tile_offsets + fq_tiles(n_bytes) - 1;  // last slot is spare
   hipLaunchKernelGGL(gf_k_fq_lens, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const int64_t*)d_nl_pos, n_newlines,
                      n_bytes, n_records, tile_counts);
-  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, tile_counts, ntiles, tile_offsets, total);
+  launch_scan(st, ntiles, tile_counts, tile_offsets, total);
   hipLaunchKernelGGL(gf_k_fq_gather, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text,
                      (const int64_t*)d_nl_pos, n_newlines, n_bytes, n_records, tile_offsets, (int64_t*)d_offsets,
                      (uint8_t*)d_bases, (uint8_t*)d_quals, cap_bytes, (unsigned long long*)d_n_bad);
@@ -1700,8 +1708,7 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   if (rc != GF_OK) return rc;
   // scalars: [0] merged bytes, [1] retries, [2] retry bytes, [3] hits, [4] hit bytes, [5] merged pairs
   hipLaunchKernelGGL(gf_k_len_tile_sums, dim3((unsigned)nctiles), dim3(GF_CTHREADS), 0, st, (const int32_t*)m_len, n, tcA, tcB);
-  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcA, nctiles, toA, scal + 0);
-  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcB, nctiles, toB, scal + 5);
+  launch_scan(st, nctiles, (const uint32_t*)tcA, toA, scal + 0, (const uint32_t*)tcB, toB, scal + 5);
   hipLaunchKernelGGL(gf_k_len_offsets, dim3((unsigned)nctiles), dim3(GF_CTHREADS), 0, st, (const int32_t*)m_len, n,
                      (const int64_t*)toA, (const int64_t*)toB, (const int64_t*)(scal + 0), m_off, m_rank, c_off);
   hipLaunchKernelGGL(gf_k_len_tail, dim3((unsigned)std::min<int64_t>((n + 256) / 256, 2048)), dim3(256), 0, st,
@@ -1725,8 +1732,7 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   P.cM = cM; P.c1 = c1; P.c2 = c2; P.mM = mM; P.m1 = m1; P.m2 = m2;
   P.gene_reversed = idx->d_gene_rev; P.n_genes = idx->table.n_genes;
   hipLaunchKernelGGL(gf_k_pair_classify, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, stt, tcA, tcB);
-  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcA, ntiles, toA, scal + 1);
-  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcB, ntiles, toB, scal + 2);
+  launch_scan(st, ntiles, (const uint32_t*)tcA, toA, scal + 1, (const uint32_t*)tcB, toB, scal + 2);
   hipLaunchKernelGGL(gf_k_pair_retry_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, (const uint8_t*)stt,
                      (const int64_t*)toA, (const int64_t*)toB, retry_cap, retry_bytes_cap, r_off, rb, rq, slot_of);
   hipLaunchKernelGGL(gf_k_pair_retry_tail, dim3((unsigned)std::min<int64_t>((retry_cap + 256) / 256, 1024)), dim3(256), 0, st,
@@ -1737,8 +1743,7 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   // 4. the matches, in push order, with their reads
   hipLaunchKernelGGL(gf_k_pair_final_count, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, (const uint8_t*)stt,
                      (const int32_t*)slot_of, (const uint8_t*)cR, (const gf_seqmatch*)mR, tcA, tcB);
-  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcA, ntiles, toA, scal + 3);
-  hipLaunchKernelGGL(gf_k_compact_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tcB, ntiles, toB, scal + 4);
+  launch_scan(st, ntiles, (const uint32_t*)tcA, toA, scal + 3, (const uint32_t*)tcB, toB, scal + 4);
   hipLaunchKernelGGL(gf_k_pair_final_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, pair_id_base,
                      (const uint8_t*)stt, (const int32_t*)slot_of, (const uint8_t*)cR, (const gf_seqmatch*)mR,
                      (const int64_t*)r_off, (const uint8_t*)rb, (const uint8_t*)rq, (const int64_t*)toA, (const int64_t*)toB,
