@@ -48,10 +48,14 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_compact_count(const uint8_t*
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = (uint32_t)total;
 }
 
-// exclusive scan of the tile totals by ONE block: 32 consecutive totals per thread (eight 16-byte loads in
-// flight, then serial), wave scans by shuffle, the 16 wave sums through LDS — 32768 totals per round, two
-// barriers.  (Eight totals per thread made five dependent rounds of the pair kernels' 39 K tiles: 62 us per scan,
-// ten scans per pack.)  Block b of the launch scans array b: the callers' scans come in pairs (bytes and reads).
+// exclusive scan of the tile totals by ONE block, 16384 totals per round: thread t takes totals t, t + 1024, ..
+// (sixteen rows of 1024, every load and store of a wavefront one contiguous run), each row is scanned inside
+// its wavefronts by shuffles, the 16 x 16 wavefront sums go through LDS where the first wavefront turns them into
+// their exclusive prefix, and every total's offset is its row-and-wavefront base plus its place in the
+// wavefront.  Three barriers per round.  (A thread owning consecutive totals — eight, then thirty-two — stored
+// its offsets 64 lanes to 64 different lines: 58-62 us for the pair kernels' 39 K tiles, most of it the one
+// CU's store path; ten such scans per pack.)  Block b of the launch scans array b: the callers' scans come in
+// pairs (bytes and reads).
 struct GfScanJob {
   const uint32_t* tile_counts;
   int64_t* tile_offsets;
@@ -60,54 +64,63 @@ struct GfScanJob {
 struct GfScanJobs { GfScanJob j[2]; };
 
 __global__ __launch_bounds__(1024) void gf_k_compact_scan(GfScanJobs jobs, int64_t ntiles) {
-  constexpr int PER = 32;
+  constexpr int ROWS = 16;
   const uint32_t* __restrict__ tile_counts = jobs.j[blockIdx.x].tile_counts;
   int64_t* __restrict__ tile_offsets = jobs.j[blockIdx.x].tile_offsets;
   int64_t* __restrict__ d_total = jobs.j[blockIdx.x].d_total;
-  __shared__ long long s_wsum[16];
+  __shared__ long long s_w[ROWS * 16];  // [row][wavefront]: sums, then their exclusive prefix
+  __shared__ long long s_round;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool vec_ok = (((uintptr_t)tile_counts) & 15u) == 0;
   long long run = 0;  // sum of all earlier rounds (the same in every thread)
-  for (int64_t b0 = 0; b0 < ntiles; b0 += 1024 * PER) {
-    const int64_t t0 = b0 + (int64_t)threadIdx.x * PER;
-    uint32_t v[PER];
-    if (vec_ok && t0 + PER <= ntiles) {
-      const uint4* q = (const uint4*)(tile_counts + t0);
+  for (int64_t b0 = 0; b0 < ntiles; b0 += 1024 * ROWS) {
+    uint32_t v[ROWS];
+    long long x[ROWS];
 #pragma unroll
-      for (int k = 0; k < PER / 4; ++k) {
-        const uint4 x = q[k];
-        v[4 * k] = x.x; v[4 * k + 1] = x.y; v[4 * k + 2] = x.z; v[4 * k + 3] = x.w;
+    for (int k = 0; k < ROWS; ++k) {
+      const int64_t e = b0 + (int64_t)k * 1024 + threadIdx.x;
+      v[k] = e < ntiles ? tile_counts[e] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+      long long y = v[k];  // inclusive scan inside the wavefront
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const long long z = __shfl_up(y, o);
+        if (lane >= o) y += z;
       }
-    } else {
-#pragma unroll
-      for (int k = 0; k < PER; ++k) v[k] = t0 + k < ntiles ? tile_counts[t0 + k] : 0u;
+      x[k] = y;
+      if (lane == 63) s_w[k * 16 + wave] = y;
     }
-    long long mine = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) mine += v[k];
-    long long x = mine;  // inclusive scan of the threads' sums within the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const long long y = __shfl_up(x, o);
-      if (lane >= o) x += y;
-    }
-    if (lane == 63) s_wsum[wave] = x;
     __syncthreads();
-    long long base = run, all = 0;
+    if (wave == 0) {  // 256 sums, four per lane, in (row, wavefront) order
+      long long a[4], mine = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const long long ws = s_wsum[w];
-      if (w < wave) base += ws;
-      all += ws;
-    }
-    long long pos = base + x - mine;
+      for (int i = 0; i < 4; ++i) {
+        a[i] = s_w[4 * lane + i];
+        mine += a[i];
+      }
+      long long y = mine;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      if (t0 + k < ntiles) tile_offsets[t0 + k] = pos;
-      pos += v[k];
+      for (int o = 1; o < 64; o <<= 1) {
+        const long long z = __shfl_up(y, o);
+        if (lane >= o) y += z;
+      }
+      long long pos = y - mine;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s_w[4 * lane + i] = pos;
+        pos += a[i];
+      }
+      if (lane == 63) s_round = y;
     }
-    run += all;
-    __syncthreads();  // s_wsum is rewritten in the next round
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+      const int64_t e = b0 + (int64_t)k * 1024 + threadIdx.x;
+      if (e < ntiles) tile_offsets[e] = run + s_w[k * 16 + wave] + x[k] - (long long)v[k];
+    }
+    run += s_round;
+    __syncthreads();  // s_w / s_round are rewritten in the next round
   }
   if (threadIdx.x == 0) *d_total = run;
 }

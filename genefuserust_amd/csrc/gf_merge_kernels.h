@@ -368,10 +368,6 @@ struct GfMergeBytes {
   uint8_t a1[5], b1[5], a2[5], b2[5];  // R1 base/quality, R2 base/quality for output bytes lane, lane+64, ..
 };
 
-// WITH_QUALS = false: the bases alone (the pair pipeline maps them and needs a merged read's qualities only for
-// the few reads that end in the hit list: gf_merged_qual).  Qualities decide a base only where the two reads
-// disagree inside the overlap (<= 2 columns of a merged pair), and are fetched there.
-template <bool WITH_QUALS>
 __device__ __forceinline__ void gf_mw_load(GfMergeBytes& g, const uint8_t* __restrict__ s1, const uint8_t* __restrict__ q1,
                                            const uint8_t* __restrict__ s2, const uint8_t* __restrict__ q2, int len1,
                                            int len2, int mlen, int offset, int k0, int lane) {
@@ -380,16 +376,14 @@ __device__ __forceinline__ void gf_mw_load(GfMergeBytes& g, const uint8_t* __res
     const int k = k0 + 64 * u + lane;
     g.a1[u] = g.b1[u] = g.a2[u] = g.b2[u] = 0;
     if (k < mlen) {
-      if (k < len1) { g.a1[u] = s1[k]; if (WITH_QUALS) g.b1[u] = q1[k]; }
-      if (k >= offset) { g.a2[u] = s2[len2 - 1 - (k - offset)]; if (WITH_QUALS) g.b2[u] = q2[len2 - 1 - (k - offset)]; }
+      if (k < len1) { g.a1[u] = s1[k]; g.b1[u] = q1[k]; }
+      if (k >= offset) { g.a2[u] = s2[len2 - 1 - (k - offset)]; g.b2[u] = q2[len2 - 1 - (k - offset)]; }
     }
   }
 }
 
-template <bool WITH_QUALS>
 __device__ __forceinline__ void gf_mw_store(const GfMergeBytes& g, uint8_t* __restrict__ os, uint8_t* __restrict__ oq,
-                                            const uint8_t* __restrict__ q1, const uint8_t* __restrict__ q2, int len1,
-                                            int len2, int mlen, int offset, int k0, int lane) {
+                                            int len1, int mlen, int offset, int k0, int lane) {
   const int olen = len1 - offset;
 #pragma unroll
   for (int u = 0; u < 5; ++u) {
@@ -401,9 +395,7 @@ __device__ __forceinline__ void gf_mw_store(const GfMergeBytes& g, uint8_t* __re
         cq = g.b2[u];
         if (k - offset < olen) {
           if (g.a1[u] != cs) {
-            const uint8_t b1 = WITH_QUALS ? g.b1[u] : q1[k];
-            const uint8_t b2 = WITH_QUALS ? cq : q2[len2 - 1 - (k - offset)];
-            if (b1 >= '?' && b2 <= '0') { cs = g.a1[u]; cq = b1; }
+            if (g.b1[u] >= '?' && cq <= '0') { cs = g.a1[u]; cq = g.b1[u]; }
           } else {
             const uint32_t q = (uint32_t)g.b1[u] + (uint32_t)cq - 33u;  // add the pair's qualities, cap at 'Z'
             cq = q >= (uint32_t)'Z' ? (uint8_t)'Z' : (uint8_t)q;
@@ -411,12 +403,12 @@ __device__ __forceinline__ void gf_mw_store(const GfMergeBytes& g, uint8_t* __re
         }
       }
       os[k] = cs;
-      if (WITH_QUALS) oq[k] = cq;
+      oq[k] = cq;
     }
   }
 }
 
-// Quality k of the merged read of a pair (read.rs:402-428), from the pair's own bytes: what gf_k_merge_write<true>
+// Quality k of the merged read of a pair (read.rs:402-428), from the pair's own bytes: what gf_k_merge_write
 // stores at out_quals[k].  Four loads at clamped positions and a selection — no branch, so that a caller's
 // unrolled loop has all its loads in flight at once.
 __device__ __forceinline__ uint8_t gf_merged_qual(const uint8_t* __restrict__ s1, const uint8_t* __restrict__ q1, int len1,
@@ -434,7 +426,6 @@ __device__ __forceinline__ uint8_t gf_merged_qual(const uint8_t* __restrict__ s1
   return k < offset ? b1 : (k >= len1 ? b2 : in_overlap);
 }
 
-template <bool WITH_QUALS>
 __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restrict__ l_bases,
                                                         const uint8_t* __restrict__ l_quals,
                                                         const int64_t* __restrict__ l_off,
@@ -478,15 +469,13 @@ __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restric
       const int mmax = mla > mlb ? mla : mlb;
       for (int k0 = 0; k0 < mmax; k0 += 320) {
         GfMergeBytes ga, gb;
-        gf_mw_load<WITH_QUALS>(ga, l_bases + s_l[e0], l_quals + s_l[e0], r_bases + s_r[e0], r_quals + s_r[e0], len1a, len2a,
-                               mla, offa, k0, lane);
-        gf_mw_load<WITH_QUALS>(gb, l_bases + s_l[ex], l_quals + s_l[ex], r_bases + s_r[ex], r_quals + s_r[ex], len1b, len2b,
-                               mlb, offb, k0, lane);
+        gf_mw_load(ga, l_bases + s_l[e0], l_quals + s_l[e0], r_bases + s_r[e0], r_quals + s_r[e0], len1a, len2a, mla,
+                   offa, k0, lane);
+        gf_mw_load(gb, l_bases + s_l[ex], l_quals + s_l[ex], r_bases + s_r[ex], r_quals + s_r[ex], len1b, len2b, mlb,
+                   offb, k0, lane);
         __builtin_amdgcn_sched_barrier(0);  // both pairs' loads before anybody's stores
-        gf_mw_store<WITH_QUALS>(ga, out_bases + s_dst[e0], WITH_QUALS ? out_quals + s_dst[e0] : nullptr, l_quals + s_l[e0],
-                                r_quals + s_r[e0], len1a, len2a, mla, offa, k0, lane);
-        gf_mw_store<WITH_QUALS>(gb, out_bases + s_dst[ex], WITH_QUALS ? out_quals + s_dst[ex] : nullptr, l_quals + s_l[ex],
-                                r_quals + s_r[ex], len1b, len2b, mlb, offb, k0, lane);
+        gf_mw_store(ga, out_bases + s_dst[e0], out_quals + s_dst[e0], len1a, mla, offa, k0, lane);
+        gf_mw_store(gb, out_bases + s_dst[ex], out_quals + s_dst[ex], len1b, mlb, offb, k0, lane);
       }
     }
   }

@@ -1490,7 +1490,7 @@ int gf_fast_merge_write_device(const gf_index* idx, const void* d_l_bases, const
   DeviceGuard guard(idx->device);
   const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 32);
   if (d_out_quals)
-    hipLaunchKernelGGL(gf_k_merge_write<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_l_bases,
+    hipLaunchKernelGGL(gf_k_merge_write, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_l_bases,
                        (const uint8_t*)d_l_quals, (const int64_t*)d_l_offsets, (const uint8_t*)d_r_bases,
                        (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int32_t*)d_len,
                        (const int64_t*)d_out_pos, (uint8_t*)d_out_bases, (uint8_t*)d_out_quals);
