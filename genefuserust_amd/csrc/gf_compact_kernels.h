@@ -83,10 +83,12 @@ __global__ __launch_bounds__(1024) void gf_k_compact_scan(GfScanJobs jobs, int64
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
       long long y = v[k];  // inclusive scan inside the wavefront
+      if (b0 + (int64_t)k * 1024 < ntiles) {  // (the same for the whole block: rows past the end hold zeros)
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const long long z = __shfl_up(y, o);
-        if (lane >= o) y += z;
+        for (int o = 1; o < 64; o <<= 1) {
+          const long long z = __shfl_up(y, o);
+          if (lane >= o) y += z;
+        }
       }
       x[k] = y;
       if (lane == 63) s_w[k * 16 + wave] = y;
