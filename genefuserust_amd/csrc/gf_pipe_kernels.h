@@ -472,6 +472,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // reach the gate.  Survivors carry the windows still standing and a flag that tells
           // gf_k_probe_filter to pass them on as they are.
           bool filt_done = false, filt_dead = false;
+          const __amdgpu_buffer_rsrc_t filter_rsrc =
+              __builtin_amdgcn_make_buffer_rsrc((void*)T.bloom, 0, (int)(T.bloom_words * 4u), 0x00020000);
+          const uint32_t filter_bytes = T.bloom_words * 4u;
           uint32_t pp[NT];
 #pragma unroll
           for (int k = 0; k < NT; ++k) pp[k] = 0;
@@ -483,6 +486,41 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 #pragma unroll
             for (int j = 0; j < PW; ++j) {
               const uint32_t whi = j + 1 < PW ? gf_cut_pk(s_pk, w0, sh, j + 1) : 0u;
+#ifndef GF_FILTER_OLD
+              // (r02 e: the kernel's vector ALUs are busy 78 % of the time and this loop is half of their
+              //  instructions.  The four answers of a word are gathered as fail bits on the even positions of one
+              //  mask and applied to the word's window byte in one go — an and-not, a compare and a shift-or per
+              //  look-up where the first form spent a dozen on compares, selects and counters; a look-up nobody
+              //  needs reads word 0, a line all lanes share, instead of branching round its load.)
+              if (!filt_dead) {
+                const uint32_t byte = (cwb[j >> 2] >> (8 * (j & 3))) & 0xFFu;  // this word's 8 windows
+                uint32_t word[4], bits[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  // windows 8j+2u and 8j+2u+1 share the 14-mer at bases 16j + 4u+2 .. 16j + 4u+15
+                  const uint32_t s14 = __builtin_amdgcn_alignbit(whi, wlo, 8u * (uint32_t)u + 4u) & 0x0FFFFFFFu;
+                  const uint32_t h2 = GF_BLOOM_HASH((s14));
+                  bits[u] = GF_BLOOM_BITS(h2);
+                  // (a buffer load: its 32-bit byte offset is the whole address computation; nwords = 0 for a
+                  //  look-up nobody needs sends it to word 0; floor(h * 4n / 2^32) & ~3 = 4 * floor(h * n / 2^32))
+                  const uint32_t nb = (byte & (3u << (2 * u))) ? filter_bytes : 0u;
+                  word[u] = __builtin_amdgcn_raw_buffer_load_b32(filter_rsrc, __umulhi(h2, nb) & ~3u, 0, 0);
+                }
+                uint32_t fail2 = 0;  // bit 2u: the filter rules out look-up u's 14-mer
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const uint32_t t = bits[u] & ~word[u];
+                  uint32_t f;  // min(t, 1): the compiler turns the C form into a compare and a select
+                  asm("v_min_u32 %0, %1, 1" : "=v"(f) : "v"(t));
+                  fail2 |= f << (2 * u);
+                }
+                const uint32_t pbyte = byte & ~(fail2 | (fail2 << 1));
+                pp[j >> 2] |= pbyte << (8 * (j & 3));
+                npos += __popc(pbyte);
+                rem -= __popc(byte);
+                filt_dead = npos + rem < GF_MAJOR_KEYS / 2;
+              }
+#else
               if (!filt_dead) {
                 const uint32_t byte = (cwb[j >> 2] >> (8 * (j & 3))) & 0xFFu;  // this word's 8 windows
                 uint32_t word[4], bits[4], both[4];
@@ -507,6 +545,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
                 }
                 filt_dead = npos + rem < GF_MAJOR_KEYS / 2;
               }
+#endif
               wlo = whi;
             }
           }
