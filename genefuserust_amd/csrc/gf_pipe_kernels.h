@@ -220,13 +220,6 @@ __device__ __forceinline__ uint32_t gf_window_mask(int nwin, int k) {
   return m >= 32 ? 0xFFFFFFFFu : (m <= 0 ? 0u : ((1u << m) - 1u));
 }
 
-// the candidate diagonals' genes fetched by the whole wavefront (see gf_k_seedverify_stream): the 10-word form,
-// whose launch reserves the staging area (launch_flat: 64 * 96 bytes per wavefront of dynamic LDS)
-#ifdef GF_GENES_DIRECT
-#define GF_GENES_COOP_PW(pw) false
-#else
-#define GF_GENES_COOP_PW(pw) ((pw) == 10)
-#endif
 #ifndef GF_SVS_WAVES_PER_SIMD
 #define GF_SVS_WAVES_PER_SIMD 4  // (four blocks per CU run anyway, see launch_flat: the registers of six are not needed)
 #endif
@@ -334,13 +327,6 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 #pragma unroll
       for (int k = 0; k < NT; ++k) e_todo[k] = 0;
       uint32_t w0 = 0, sh = 0;
-      // state of a read that reaches the main path, kept across the wave-wide gene fetch between its two halves
-      bool active = false, filt_done = false, filt_dead = false;
-      int L = 0, nvalid = 0;
-      uint32_t pos = 0, anybad = 0, K = GF_NONE_LIN;
-      uint32_t cwb[NT], pp[NT];
-#pragma unroll
-      for (int k = 0; k < NT; ++k) cwb[k] = pp[k] = 0;
 #if defined(GF_ABLATE_SV) && GF_ABLATE_SV == 6  // timing only: staging and conversion, one LDS word per read
       if (in_range) counts[r] = s_pk[((uint32_t)(off0 - base_off) + mis) >> 4] == 0x1234567u ? 1 : 0;
       if (false) {
@@ -358,12 +344,12 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
         } else if (len64 < GF_KMER + 2 * (GF_MAJOR_KEYS / 2 - 1)) {
           counts[r] = 0;  // fewer than 20 stride-2 windows: count1 < 20 whatever they hit
         } else {
-          active = true;
-          L = (int)len64;
-          pos = (uint32_t)(off0 - base_off) + mis;
+          const int L = (int)len64;
+          const uint32_t pos = (uint32_t)(off0 - base_off) + mis;
           w0 = pos >> 4;
           sh = 2u * (pos & 15u);
           // does the read hold any base outside A/C/G/T?  (flag bits pos .. pos+L-1)
+          uint32_t anybad = 0;
           {
             const uint32_t v0 = pos >> 5, vs = pos & 31u;
             uint32_t lo = s_iv[v0];
@@ -379,6 +365,8 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           }
           // pass A: the clean stride-2 windows (all 16 bases usable), one bit per window, and
           // the seeds at bases 0, 32, 64, 96
+          uint32_t cwb[NT];
+          int nvalid;
           uint32_t key[4];
           uint32_t okm = 0;
 #pragma unroll
@@ -420,7 +408,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // of window 16s+1: a clear bit pair proves that neither can vote, which spares the filter
           // pass those windows.
           uint32_t kill[2] = {0, 0};  // windows 0..63 proven unable to vote (seeds sit at windows 0, 16, 32, 48)
-          // K: candidate diagonal = site code of read base 0
+          uint32_t K = GF_NONE_LIN;   // candidate diagonal: site code of read base 0
           // Seed 0 first — filter, then its bucket: most reads that have a candidate diagonal get it
           // here, for one filter line into the L1 instead of four (the kernel is bound by those line
           // fills); the other three seeds are asked about only by the reads still without one.
@@ -483,9 +471,13 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // per step, two windows per look-up; stops when even the windows not asked yet cannot
           // reach the gate.  Survivors carry the windows still standing and a flag that tells
           // gf_k_probe_filter to pass them on as they are.
+          bool filt_done = false, filt_dead = false;
           const __amdgpu_buffer_rsrc_t filter_rsrc =
               __builtin_amdgcn_make_buffer_rsrc((void*)T.bloom, 0, (int)(T.bloom_words * 4u), 0x00020000);
           const uint32_t filter_bytes = T.bloom_words * 4u;
+          uint32_t pp[NT];
+#pragma unroll
+          for (int k = 0; k < NT; ++k) pp[k] = 0;
 #ifndef GF_SV_NO_INLINE_FILTER
           if (K == GF_NONE_LIN && T.bloom_in_l2 == 2) {
             filt_done = true;
@@ -558,48 +550,6 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             }
           }
 #endif
-        }
-      }
-      // The genes of the candidate diagonals, fetched by the whole wavefront: a read's PW + 1 (gd word, ub2 word)
-      // pairs are 8 * (PW + 1) consecutive bytes.  Each lane loading its own eleven pairs touched its one or two
-      // lines eleven times, ten of them while the line was still on its way; here eight lanes share a read —
-      // 16 bytes each, one contiguous run per read and instruction — the pieces go through the wave's LDS
-      // staging area (dynamic LDS) and every lane picks its pairs up from there.
-      uint2 gw[PW + 1];
-#pragma unroll
-      for (int j = 0; j < PW + 1; ++j) gw[j] = make_uint2(0u, 0u);
-      if constexpr (GF_GENES_COOP_PW(PW)) {
-        extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-        constexpr int GB = ((8 * (PW + 1) + 8 + 15) / 16) * 16;  // bytes staged per read (16-byte pieces from 16 below)
-        constexpr int GC = GB / 16;                              // pieces per read (<= 8)
-        uint8_t* s_genes = s_dyn + (size_t)wave * 64 * GB;
-        const bool hasK = active && K != GF_NONE_LIN;
-        const uint32_t kw = hasK ? (K >> 4) : 0xFFFFFFFFu;  // index of the read's first pair
-        if (__ballot(hasK) != 0) {
-          gf_wave_lds_sync();  // (the previous tile's reads of the area are done)
-          uint4 piece[8];
-          uint32_t kwr[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {  // instruction i: reads 8i .. 8i+7, lane l -> read 8i + l/8, piece l%8
-            kwr[i] = (uint32_t)__shfl((int)kw, 8 * i + (lane >> 3));
-            piece[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (kwr[i] != 0xFFFFFFFFu && (lane & 7) < GC)
-              piece[i] = *(const uint4*)((const uint8_t*)T.gdu + ((size_t)kwr[i] * 8 & ~(size_t)15) + 16 * (lane & 7));
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if (kwr[i] != 0xFFFFFFFFu && (lane & 7) < GC)
-              *(uint4*)(s_genes + (size_t)(8 * i + (lane >> 3)) * GB + 16 * (lane & 7)) = piece[i];
-          gf_wave_lds_sync();
-          if (hasK) {
-            const uint8_t* mine = s_genes + (size_t)lane * GB + 8 * (kw & 1u);
-#pragma unroll
-            for (int j = 0; j < PW + 1; ++j) gw[j] = *(const uint2*)(mine + 8 * j);
-          }
-        }
-      }
-      if (active) {
-        {
           // pass B: verify the candidate diagonal against the genes in site-code space, a
           // word of the read at a time: window w counts iff its 16 bases equal the bases of
           // site K + 2w and that site is the only site of its key
@@ -607,12 +557,11 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 #pragma unroll
           for (int k = 0; k < NT; ++k) vmb[k] = 0;
           if (K != GF_NONE_LIN) {
+            const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
             const uint32_t bo = 2u * (K & 15u);
-            if constexpr (!GF_GENES_COOP_PW(PW)) {
-              const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
+            uint2 gw[PW + 1];
 #pragma unroll
-              for (int j = 0; j < PW + 1; ++j) gw[j] = gp[j];
-            }
+            for (int j = 0; j < PW + 1; ++j) gw[j] = gp[j];
             uint32_t zz_cur;
             {
               const uint32_t x = gf_cut_pk(s_pk, w0, sh, 0) ^ __builtin_amdgcn_alignbit(gw[1].x, gw[0].x, bo);

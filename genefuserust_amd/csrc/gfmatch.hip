@@ -347,9 +347,8 @@ static int launch_flat(const gf_index* idx, const GfTable& T, hipStream_t st, co
   if (ev) GF_HIP(hipEventRecord(ev[0], st));
   // Seed+verify is bound by the line fills of its CU's L1, not by waves in flight: four blocks
   // per CU (40 KB of LDS each, padded with dynamic LDS) measured 2.5 % faster than six.
-  // (the 10-word form's gene staging area lives there: 4 wavefronts x 64 reads x 96 bytes)
-  size_t pad_lds = PW == 10 ? 24576 : 0;
-  if (const char* e = getenv("GF_SV_PAD_LDS")) pad_lds = std::max<size_t>(pad_lds, (size_t)atoi(e));  // experiments (more only)
+  size_t pad_lds = PW == 10 ? 24000 : 0;
+  if (const char* e = getenv("GF_SV_PAD_LDS")) pad_lds = (size_t)atoi(e);  // experiments
   hipLaunchKernelGGL((gf_k_seedverify_stream<PW, PACKED>), dim3(p.nblk), dim3(256), pad_lds, st, T, bases, src.pk, src.iv, offsets, n,
                      lmax, batch_max, counts, (GfPipeEntryW<PW>*)w.list_b, w.blk_cnt, p.per_block, w.list_long, w.ctr);
   if (ev) GF_HIP(hipEventRecord(ev[1], st));
