@@ -35,6 +35,11 @@ def main():
         bases, quals, off, diff = fast_merge_device(ix, *t, hint)
         torch.cuda.synchronize()
         b, q, o, d = bases.cpu().numpy().tobytes(), quals.cpu().numpy().tobytes(), off.cpu().numpy(), diff.cpu().numpy()
+        b2 = fast_merge_device(ix, *t, hint, with_quals=False)[0]   # the pair pipeline's bases-only writer
+        torch.cuda.synchronize()
+        if b2.cpu().numpy().tobytes() != b:
+            print("MERGE MISMATCH round", rd, ": the bases-only writer differs from the byte-per-lane writer")
+            return 1
         for i, p in enumerate(pairs):
             w = oracle_py.fast_merge(*p)
             g = (b[o[i]:o[i + 1]], q[o[i]:o[i + 1]], int(d[i])) if o[i + 1] > o[i] else None
