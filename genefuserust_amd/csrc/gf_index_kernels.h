@@ -7,7 +7,10 @@
 // (position -(f+15), windows 1..len-16; the reverse window i of indexer.rs:168
 // is the forward window f = len-16-i, so position = i+1-len = -(f+15)).
 // Keys seen once keep their site, 2..5 times keep all sites, >= 6 times become
-// HIGH.  Three passes over the gene bases, no sort:
+// HIGH.  No sort.  One pass over the gene bases (gf_k_index_insert: a key's first site is written with the
+// claim of its slot, later sites go to a side list), a sweep over the table (counters -> unique /
+// dupes(start in dupes[]) / HIGH, statistics), the side list into the duplicate lists.  The first form is kept
+// behind GF_BUILD_TWO_PASS (experiments):
 //   COUNT   insert keys with 64-bit CAS, count occurrences
 //   classify (count -> unique / dupes(start in dupes[]) / HIGH)
 //   FILL    write site codes
@@ -229,6 +232,205 @@ __global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_sites(GfGenes G, 
   }
 }
 
+// ---- the one-pass build: claim and site in one touch of the bucket ----
+// 97 % of the keys of a gene set have one site.  The COUNT / FILL pair touches every site's bucket twice — both
+// random 64-byte lines far from every cache — to learn the count before a site may be written.  Here the thread
+// that claims a slot writes its site with the claim (the final form of a key with one site); a thread that finds
+// its key already there turns the slot into a counter (the first site moves to a side list with the thread's
+// own) or bumps it and adds its site to the list.  A sweep then hands out the duplicate lists, and the side list
+// — the 3 % — fills them.  "Unique" flags are set with the claim and cleared again for every site on the list.
+struct GfSideEntry { uint32_t key, lin; };
+
+// true: the slot was claimed for (key, lin), which is so far the key's only site; false: the key was there, the
+// site (and, for the thread that found the key with one site, that site) went to e0 / e1, ne = how many
+__device__ __forceinline__ bool gf_insert_site(uint64_t* slots, uint32_t nbuckets, uint32_t key, uint32_t lin,
+                                               GfSideEntry& e0, GfSideEntry& e1, int& ne) {
+  uint32_t b = gf_bucket_of(key, nbuckets);
+  const uint32_t mine = (GF_TYPE_UNIQUE << GF_TYPE_SHIFT) | (lin & GF_LIN_MASK);
+  ne = 0;
+  for (uint32_t guard = 0; guard <= nbuckets; ++guard) {
+    uint64_t* bucket = slots + (size_t)b * GF_SLOTS_PER_BUCKET;
+    const uint4* q = (const uint4*)bucket;  // a snapshot (see gf_insert_count)
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const uint32_t lo[8] = {q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.z};
+    const uint32_t hi[8] = {q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.y, q3.w};
+    int at = -1, first_empty = GF_SLOTS_PER_BUCKET;
+#pragma unroll
+    for (int j = GF_SLOTS_PER_BUCKET - 1; j >= 0; --j) {
+      if ((lo[j] & GF_VAL_LOW) == 0) first_empty = j;
+      else if (hi[j] == key) at = j;
+    }
+    if (at < 0) {
+      for (int j = first_empty; j < GF_SLOTS_PER_BUCKET; ++j) {
+        uint64_t cur = j == first_empty ? 0ull : gf_atomic_load64(bucket + j);
+        if ((cur & GF_VAL_LOW) == 0) {
+          const uint64_t want = ((uint64_t)key << 32) | mine;
+          const uint64_t prev = atomicCAS((unsigned long long*)(bucket + j), 0ull, (unsigned long long)want);
+          if (prev == 0) return true;
+          cur = prev;
+        }
+        if ((uint32_t)(cur >> 32) == key) {
+          at = j;
+          break;
+        }
+      }
+      if (at < 0) {
+        atomicOr((unsigned int*)bucket, GF_VAL_OVF);  // slot 0, low word
+        b = (b + 1 == nbuckets) ? 0 : b + 1;
+        continue;
+      }
+    }
+    // a later site of a key that is there
+    unsigned int* lop = (unsigned int*)(bucket + at);
+    uint32_t cur = __hip_atomic_load(lop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      if (((cur & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) {
+        const uint32_t want = (cur & GF_VAL_OVF) | 2u;  // counter form: two sites
+        const uint32_t prev = atomicCAS(lop, cur, want);
+        if (prev == cur) {
+          e0.key = key; e0.lin = cur & GF_LIN_MASK;
+          e1.key = key; e1.lin = lin;
+          ne = 2;
+          return false;
+        }
+        cur = prev;  // turned into a counter by somebody else, or the bucket's overflow flag was set meanwhile
+      } else {
+        atomicAdd(lop, 1u);
+        e0.key = key; e0.lin = lin;
+        ne = 1;
+        return false;
+      }
+    }
+  }
+  return false;
+}
+
+#define GF_SIDE_LDS 2048  // side-list entries a block gathers before it takes room in the global list (one atomic)
+
+__device__ __forceinline__ unsigned int gf_ix_wave_append_lds(bool want, unsigned int* s_counter) {
+  const uint64_t m = __ballot(want);
+  unsigned int base = 0;
+  if (m) {
+    const int leader = __builtin_ctzll(m);
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(s_counter, (unsigned int)__popcll(m));
+    base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+  }
+  return base + (unsigned int)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+}
+
+// the tile loop of gf_k_index_sites with gf_insert_site; side / side_n: the global list and its fill (entries
+// beyond side_cap are counted, not written: the host checks the count)
+__global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_index_insert(GfGenes G, uint64_t* slots, uint32_t nbuckets,
+                                                                      uint32_t* gdu, uint32_t* bloom,
+                                                                      uint32_t bloom_words, GfSideEntry* side,
+                                                                      unsigned long long* side_n,
+                                                                      unsigned long long side_cap) {
+  __shared__ uint32_t s_codes[GF_TILE_BASES / 16 + 2];
+  __shared__ uint32_t s_inv[GF_TILE_BASES / 32 + 2];
+  __shared__ GfSideEntry s_side[GF_SIDE_LDS];
+  __shared__ unsigned int s_fill;
+  __shared__ unsigned long long s_base;
+  const uint32_t t0 = blockIdx.x * GF_TILE_BASES;
+  const int tid = threadIdx.x;
+  for (int ch = tid; ch < GF_TILE_BASES / 16 + 1; ch += GF_INDEX_THREADS) {
+    uint4 q = *(const uint4*)(G.cat + (size_t)t0 + 16u * ch);
+    uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+    gf_convert4(q.x, c0, i0);
+    gf_convert4(q.y, c1, i1);
+    gf_convert4(q.z, c2, i2);
+    gf_convert4(q.w, c3, i3);
+    s_codes[ch] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+    ((uint16_t*)s_inv)[ch] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+  }
+  if (tid == 0) {
+    s_codes[GF_TILE_BASES / 16 + 1] = 0;
+    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 1] = 0xFFFF;
+    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 2] = 0xFFFF;
+    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 3] = 0xFFFF;
+    s_fill = 0;
+  }
+  __syncthreads();
+  auto flush = [&]() {  // (called by the whole block, between barriers)
+    const unsigned int nf = s_fill;
+    if (tid == 0 && nf) s_base = atomicAdd(side_n, (unsigned long long)nf);
+    __syncthreads();
+    for (unsigned int i = tid; i < nf; i += GF_INDEX_THREADS)
+      if (s_base + i < side_cap) side[s_base + i] = s_side[i];
+    __syncthreads();
+    if (tid == 0) s_fill = 0;
+    __syncthreads();
+  };
+  for (int l0 = 0; l0 < GF_TILE_BASES; l0 += GF_INDEX_THREADS) {  // (every lane of a wave stays in the loop)
+    const int l = l0 + tid;
+    const uint32_t g = t0 + (uint32_t)l;
+    bool fwd = false, rev = false, next_has = false;
+    uint32_t key = 0, lin_f = 0, lin_r = 0;
+    if (g < G.total) {
+      const uint32_t sh = (uint32_t)l & 31u;
+      const uint32_t lo_w = s_inv[l >> 5], hi_w = s_inv[(l >> 5) + 1];
+      const uint32_t inv = sh ? ((lo_w >> sh) | (hi_w << (32u - sh))) : lo_w;
+      if ((inv & 0xFFFFu) == 0) {
+        int lo = 0, hi = G.n_genes;  // invariant gene_off[lo] <= g < gene_off[hi]
+        while (hi - lo > 1) {
+          int mid = (lo + hi) >> 1;
+          if (G.gene_off[mid] <= g) lo = mid; else hi = mid;
+        }
+        const uint32_t f = g - G.gene_off[lo];
+        const uint32_t len = G.gene_off[lo + 1] - G.gene_off[lo];
+        if (f + GF_KMER <= len) {
+          key = gf_window(s_codes[l >> 4], s_codes[(l >> 4) + 1], (uint32_t)l);
+          fwd = f + GF_KMER < len;
+          rev = f >= 1;
+          lin_f = G.lin_base[lo] + f;
+          lin_r = G.lin_base[lo] - (f + 15u);
+          next_has = ((inv >> 2) & 0xFFFFu) == 0 && f + 2 + GF_KMER <= len && l + 2 + GF_KMER <= GF_TILE_BASES + 16;
+        }
+      }
+    }
+    GfSideEntry ef0{0, 0}, ef1{0, 0}, er0{0, 0}, er1{0, 0};
+    int nf = 0, nr = 0;
+    const bool cf = fwd && gf_insert_site(slots, nbuckets, key, lin_f, ef0, ef1, nf);
+    const bool cr = rev && gf_insert_site(slots, nbuckets, gf_revcomp_key(key), lin_r, er0, er1, nr);
+    gf_wave_set_unique(gdu, cf, lin_f);
+    gf_wave_set_unique(gdu, cr, lin_r);
+    if (bloom && (fwd || rev)) {
+      gf_bloom_insert(bloom, bloom_words, key & 0x0FFFFFFFu);
+      if (!next_has) gf_bloom_insert(bloom, bloom_words, key >> 4);
+    }
+    // the side entries of this round into the block's buffer (at most four per thread: it has room for them)
+    {
+      unsigned int at;
+      at = gf_ix_wave_append_lds(nf > 0, &s_fill); if (nf > 0) s_side[at] = ef0;
+      at = gf_ix_wave_append_lds(nf > 1, &s_fill); if (nf > 1) s_side[at] = ef1;
+      at = gf_ix_wave_append_lds(nr > 0, &s_fill); if (nr > 0) s_side[at] = er0;
+      at = gf_ix_wave_append_lds(nr > 1, &s_fill); if (nr > 1) s_side[at] = er1;
+    }
+    // (a barrier that ORs the threads' views: one that looks early may see less than the round's total, the
+    //  last one to append sees it all, and every thread gets the same answer)
+    if (__syncthreads_or(s_fill > GF_SIDE_LDS - 4 * GF_INDEX_THREADS)) flush();
+  }
+  __syncthreads();
+  flush();
+}
+
+// The side list: every site of every key with more than one.  Keys with 2..5 sites get them into their list
+// (assigned by the sweep); every listed site loses the "unique" flag its claim may have set.
+__global__ void gf_k_index_side(const GfSideEntry* __restrict__ side, unsigned long long n, uint64_t* slots,
+                                uint32_t nbuckets, uint32_t* dupes, uint32_t* gdu) {
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const GfSideEntry e = side[i];
+    atomicAnd(gdu + 2 * (size_t)(e.lin >> 4) + 1, ~(1u << (2u * (e.lin & 15u))));
+    uint64_t* s = gf_find_slot(slots, nbuckets, e.key);
+    if (!s) continue;
+    const uint32_t val = *(const uint32_t*)s;
+    if (((val & GF_VAL_LOW) >> GF_TYPE_SHIFT) != GF_TYPE_DUPES) continue;
+    const uint32_t cnt = (val >> GF_DUPE_COUNT_SHIFT) & 7u, start = val & GF_DUPE_START_MASK;
+    for (uint32_t k = 0; k < cnt; ++k)
+      if (atomicCAS(dupes + start + k, GF_DUPE_EMPTY, e.lin) == GF_DUPE_EMPTY) break;
+  }
+}
+
 // Both strands of the genes in site-code space (the even words of gdu, layout: gf_table.h), used by the diagonal
 // verification of the mapping kernels.  A thread writes one word = 16 consecutive site codes of one gene's
 // region [lin_base - len + 1, lin_base + len - 1]: codes >= lin_base are the forward bases f = code - lin_base,
@@ -318,7 +520,7 @@ __global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uin
   uint32_t keys = 0, uniq = 0, dk = 0, high = 0, ds = 0;
   for (uint64_t it = 0; it < rounds; ++it) {
     const uint64_t b = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t val[GF_SLOTS_PER_BUCKET], want[GF_SLOTS_PER_BUCKET];
+    uint32_t val[GF_SLOTS_PER_BUCKET], want[GF_SLOTS_PER_BUCKET], cnt_of[GF_SLOTS_PER_BUCKET];
     uint32_t mine = 0;
     uint64_t* base_slot = slots + b * GF_SLOTS_PER_BUCKET;
     if (b < nbuckets) {
@@ -332,7 +534,11 @@ __global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uin
     }
 #pragma unroll
     for (int k = 0; k < GF_SLOTS_PER_BUCKET; ++k) {
-      const uint32_t c = val[k] & GF_VAL_LOW;
+      // a slot holds a count (two-pass build, or a key the one-pass build found more than once), or — one-pass
+      // build — the site of a key claimed once: type UNIQUE already, count 1
+      const bool claimed = ((val[k] & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE;
+      const uint32_t c = claimed ? 1u : (val[k] & GF_VAL_LOW);
+      cnt_of[k] = c;
       want[k] = (c >= 2 && c <= GF_DUP_THRESHOLD) ? c : 0u;
       mine += want[k];
       sites += c;
@@ -362,10 +568,11 @@ __global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uin
     if (b < nbuckets) {
 #pragma unroll
       for (int k = 0; k < GF_SLOTS_PER_BUCKET; ++k) {
-        const uint32_t c = val[k] & GF_VAL_LOW;
+        const uint32_t c = cnt_of[k];
         if (!c) continue;
         uint32_t nv;
         if (c == 1) {
+          if (((val[k] & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) continue;  // claimed with its site: final
           nv = GF_TYPE_UNIQUE << GF_TYPE_SHIFT;
         } else if (c <= GF_DUP_THRESHOLD) {
           nv = (GF_TYPE_DUPES << GF_TYPE_SHIFT) | (c << GF_DUPE_COUNT_SHIFT) | (start & GF_DUPE_START_MASK);

@@ -530,24 +530,11 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   hipLaunchKernelGGL(gf_k_index_strands, dim3((unsigned)((gd_words + 255) / 256)), dim3(256), 0, 0, G,
                      (const uint32_t*)ix->d_lin_hi, ix->d_gdu, (uint32_t)gd_words);
   GF_HIP(hipGetLastError());
-  if (ntiles > 0) {
-    hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_COUNT>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
-                       ix->d_slots, nbuckets, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
-    GF_HIP(hipGetLastError());
-  }
-  // the duplicate lists are sized before their keys are counted: every site could be in one (the block comes
-  // from the cache of freed indexes in multi-CSV mode); the sweep that assigns them counts the keys on its way
-  const uint64_t dupes_cap = std::max<uint64_t>(std::min<uint64_t>(site_bound, (uint64_t)GF_DUPE_START_MASK + 1), 1);
-  GF_HIP(block_alloc(dev, (void**)&ix->d_dupes, dupes_cap * sizeof(uint32_t)));
-  hipLaunchKernelGGL(gf_k_classify_assign, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
-  GF_HIP(hipGetLastError());
-  GF_HIP(hipMemcpy(stats, d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
-  lap("strands, count pass, list assignment + statistics");
-  const uint64_t n_dupe_sites = stats[5];
-  if (n_dupe_sites > (uint64_t)GF_DUPE_START_MASK)
-    return fail(GF_ERR_CAPACITY, "too many duplicated sites for the 26-bit duplicate index");
-  GF_HIP(hipMemsetAsync(ix->d_dupes, 0xFF, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t), 0));
-  // presence filter over canonical 14-mers, filled by the FILL pass.  Indexes up to ~14 M keys: <= GF_BLOOM_KIB
+  // One pass (default): a site is written with the claim of its key's slot; the sites of keys found again go
+  // through a side list (gf_index_kernels.h).  GF_BUILD_TWO_PASS=1: the COUNT / FILL pair (experiments).
+  static const bool two_pass = getenv("GF_BUILD_TWO_PASS") != nullptr;
+  uint32_t bloom_words = 0, bloom_in_l2 = 0;
+  // presence filter over canonical 14-mers, filled with the sites.  Indexes up to ~14 M keys: <= GF_BLOOM_KIB
   // (default 3 MiB) so that it lives in every XCD's L2, and seed+verify runs the filter pass for reads
   // without a candidate diagonal itself.  Up to ~30 M keys: 2.2 bits per key, up to
   // GF_BLOOM_MID_KIB (default 8 MiB) — no longer L2-resident, but still mostly L2 hits: used for
@@ -556,13 +543,13 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   // GF_BLOOM_BIG_BPK (default 4) bits per key, resident in the Infinity Cache and used by the
   // filter kernel only — a lookup is then an L2-missing request like a bucket probe, but one
   // lookup answers for two windows and a negative answer spares both bucket probes.
-  uint32_t bloom_words = 0, bloom_in_l2 = 0;
-  {
+  // (`keys`: the number of keys where it is known before the filter is filled — the two-pass build — and the
+  // number of sites, 3 % more on these gene sets, where it is not.)
+  auto make_filter = [&](uint64_t keys) -> int {
     size_t kib = 3072, mid_kib = 8192, big_bpk = 4;
     if (const char* e = getenv("GF_BLOOM_KIB")) kib = (size_t)atol(e);
     if (const char* e = getenv("GF_BLOOM_MID_KIB")) mid_kib = (size_t)atol(e);
     if (const char* e = getenv("GF_BLOOM_BIG_BPK")) big_bpk = (size_t)atol(e);
-    const uint64_t keys = stats[1];
     const uint64_t cap_words = (uint64_t)kib * 1024 / 4, mid_words = (uint64_t)mid_kib * 1024 / 4;
     const uint64_t want_words = keys * 7 / 128;  // 1.75 bits per key: what the L2-resident form needs at least
     // beyond that: 2.2 bits per key — at 1.75 half of the background reads outlive the filter and
@@ -584,15 +571,57 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     if (words) {
       bloom_words = (uint32_t)words;
       GF_HIP(block_alloc(dev, (void**)&ix->d_bloom, (size_t)bloom_words * sizeof(uint32_t)));
-      GF_HIP(hipMemset(ix->d_bloom, 0, (size_t)bloom_words * sizeof(uint32_t)));
+      GF_HIP(hipMemsetAsync(ix->d_bloom, 0, (size_t)bloom_words * sizeof(uint32_t), 0));
     }
-  }
-  if (ntiles > 0) {
-    hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_FILL>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
-                       ix->d_slots, nbuckets, ix->d_dupes, ix->d_gdu, ix->d_bloom, bloom_words);
+    return GF_OK;
+  };
+  // the duplicate lists are sized before their keys are counted: every site could be in one (the block comes
+  // from the cache of freed indexes in multi-CSV mode); the sweep that assigns them counts the keys on its way
+  const uint64_t dupes_cap = std::max<uint64_t>(std::min<uint64_t>(site_bound, (uint64_t)GF_DUPE_START_MASK + 1), 1);
+  GF_HIP(block_alloc(dev, (void**)&ix->d_dupes, dupes_cap * sizeof(uint32_t)));
+  struct SideBlock { int dev; GfSideEntry* p = nullptr; ~SideBlock() { if (p) { (void)hipDeviceSynchronize(); block_free(dev, p); } } } d_side{dev};
+  const uint64_t side_cap = std::max<uint64_t>(site_bound, 1);
+  uint64_t n_side = 0;
+  if (!two_pass) {
+    if (int rc = make_filter(site_bound)) return rc;
+    GF_HIP(block_alloc(dev, (void**)&d_side.p, side_cap * sizeof(GfSideEntry)));
+    if (ntiles > 0) {
+      hipLaunchKernelGGL(gf_k_index_insert, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G, ix->d_slots, nbuckets, ix->d_gdu,
+                         ix->d_bloom, bloom_words, d_side.p, d_stats.p + 7, (unsigned long long)side_cap);
+      GF_HIP(hipGetLastError());
+    }
+  } else if (ntiles > 0) {
+    hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_COUNT>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
+                       ix->d_slots, nbuckets, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     GF_HIP(hipGetLastError());
   }
-  lap("fill pass (sites, unique flags, filter)");
+  hipLaunchKernelGGL(gf_k_classify_assign, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
+  GF_HIP(hipGetLastError());
+  GF_HIP(hipMemcpy(stats, d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
+  lap(two_pass ? "strands, count pass, list assignment + statistics" : "strands, insert pass (sites, flags, filter), list assignment + statistics");
+  const uint64_t n_dupe_sites = stats[5];
+  if (n_dupe_sites > (uint64_t)GF_DUPE_START_MASK)
+    return fail(GF_ERR_CAPACITY, "too many duplicated sites for the 26-bit duplicate index");
+  GF_HIP(hipMemsetAsync(ix->d_dupes, 0xFF, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t), 0));
+  if (!two_pass) {
+    n_side = stats[7];
+    if (n_side > side_cap) return fail(GF_ERR_CAPACITY, "side list of the index build overflowed");
+    if (n_side > 0) {
+      const int grid = (int)std::min<uint64_t>((n_side + 255) / 256, (uint64_t)ix->n_cus * 16);
+      hipLaunchKernelGGL(gf_k_index_side, dim3(grid), dim3(256), 0, 0, (const GfSideEntry*)d_side.p, (unsigned long long)n_side,
+                         ix->d_slots, nbuckets, ix->d_dupes, ix->d_gdu);
+      GF_HIP(hipGetLastError());
+    }
+    lap("side list (duplicate lists, flags)");
+  } else {
+    if (int rc = make_filter(stats[1])) return rc;
+    if (ntiles > 0) {
+      hipLaunchKernelGGL(gf_k_index_sites<GF_MODE_FILL>, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G,
+                         ix->d_slots, nbuckets, ix->d_dupes, ix->d_gdu, ix->d_bloom, bloom_words);
+      GF_HIP(hipGetLastError());
+    }
+    lap("fill pass (sites, unique flags, filter)");
+  }
   hipLaunchKernelGGL(gf_k_sort_dupes, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_dupes);
   GF_HIP(hipGetLastError());
   GF_HIP(hipDeviceSynchronize());
