@@ -139,6 +139,57 @@ def test_strands_flags_and_filter_word_by_word(gpu_device):
         ix.close()
 
 
+def test_repeat_heavy_genes_through_the_side_list(gpu_device):
+    """Genes that are almost nothing but repeats: nearly every site is a later site of its key, so the one-pass
+    build's side list takes them all (block buffers flushed many times per tile, counters bumped by thousands of
+    threads at once) — strands, flags, filter and statistics still equal the host rebuild, and every key answers
+    with its sites (2..5-fold) or none (>= 6-fold), like the reference's m_dupe_list / the HIGH mark."""
+    from genefuserust_amd import Indexer
+    rng = np.random.default_rng(99)
+
+    def rnd(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n))
+    unit3 = rnd(700)
+    genes = [b"ACGTTGCA" * 6000,            # 8 distinct windows per strand, thousands of sites each: all HIGH
+             b"A" * 20000,                   # one key (and its reverse complement), 20 K sites each
+             unit3 * 3 + rnd(40),            # every key of the unit three times: 2..5-fold lists
+             rnd(500) + unit3 + rnd(500),    # ... a fourth time, in another gene
+             b"N" * 3000,                    # nothing to index
+             rnd(5000)]
+    ix = Indexer.from_gene_slices(genes)
+    ix.make_index()
+    try:
+        gdu, filt, lin_base = _export(ix, 0), _export(ix, 1), _export(ix, 2)
+        gd_words = gdu.shape[0] // 2
+        even, flags, want_filter, sites = _expected(genes, lin_base, gd_words, filt.shape[0])
+        assert (gdu[0::2] == even).all() and (gdu[1::2] == flags).all() and (filt == want_filter).all()
+        info = ix.info()
+        assert info["n_keys"] == len(sites) and info["n_sites"] == sum(len(v) for v in sites.values())
+        assert info["n_unique"] == sum(1 for v in sites.values() if len(v) == 1)
+        assert info["n_dupe_keys"] == sum(1 for v in sites.values() if 2 <= len(v) <= 5) >= 600
+        assert info["n_high_keys"] == sum(1 for v in sites.values() if len(v) >= 6) >= 10
+        assert info["n_dupe_sites"] == sum(len(v) for v in sites.values() if 2 <= len(v) <= 5)
+        # every key through the look-up: device keys -> reference-coded k-mers is a bijection the library owns,
+        # so ask with the windows themselves
+        def ref_kmer(key):   # device key (base 0 in the low bits, A0 C1 T2 G3) -> indexer.rs:789-913 coding
+            out = 0
+            for k in range(16):
+                c = (key >> (2 * k)) & 3
+                out = (out << 2) | {0: 0, 1: 2, 2: 1, 3: 3}[c]
+            return out
+        keys = list(sites.keys())
+        sample = [keys[i] for i in rng.choice(len(keys), size=min(len(keys), 3000), replace=False)]
+        cnt, ctg, pos = ix.lookup(np.array([ref_kmer(k) for k in sample], dtype=np.uint32))
+        for j, k in enumerate(sample):
+            n = len(sites[k])
+            assert int(cnt[j]) == (n if n <= 5 else -2), (hex(k), n, int(cnt[j]))   # -2: the HIGH mark
+            if 2 <= n <= 5:   # the list holds exactly the key's sites (as site codes: contig / position -> code)
+                got = sorted(int(lin_base[int(ctg[j, t])]) + int(pos[j, t]) for t in range(n))
+                assert got == sorted(sites[k]), (hex(k), got, sorted(sites[k]))
+    finally:
+        ix.close()
+
+
 def test_export_rejects_unknown_array(gpu_device):
     from genefuserust_amd import Indexer, _lib
     ix = Indexer.from_gene_slices([b"ACGTTGCA" * 8])
