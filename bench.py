@@ -401,8 +401,10 @@ def roofline_object(args, cfg, n, L, kern_ms_avg, stage_ms):
     measured = traffic / (kern_ms_avg * 1e-3) / 1e9 if traffic else None
     return {
         "bound": "hbm",
-        "binding_resource": "not HBM streaming: VALU issue and L1 line fills of scattered 4-byte filter look-ups "
-                            "(DESIGN.md §5/§9); the pass moves a third of the algorithmic bytes",
+        "binding_resource": "not HBM streaming (the pass moves a third of the algorithmic bytes): each tile's chain of "
+                            "dependent look-ups (seed filter, bucket, filter rounds, genes) at the latencies of a loaded "
+                            "memory system; neither VALU issue (-9 % instructions: -1 % time), occupancy (4..8 blocks per "
+                            "CU: flat) nor the L2's look-up rate (56 % of 269 G/s) is saturated (DESIGN.md §5)",
         "kernel": {0: "gf_map_reads_device = 4 kernels: gf_k_seedverify_stream + gf_k_probe_filter + "
                       "gf_k_probe_buckets + gf_k_map_reads_list; achieved uses their summed duration",
                    1: "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
