@@ -220,6 +220,9 @@ __device__ __forceinline__ uint32_t gf_window_mask(int nwin, int k) {
   return m >= 32 ? 0xFFFFFFFFu : (m <= 0 ? 0u : ((1u << m) - 1u));
 }
 
+#ifndef GF_FILTER_AUX
+#define GF_FILTER_AUX 0  // cache policy bits of the inline filter's buffer loads (experiments: 1 sc0, 2 nt, 16 sc1)
+#endif
 #ifndef GF_SVS_WAVES_PER_SIMD
 #define GF_SVS_WAVES_PER_SIMD 4  // (four blocks per CU run anyway, see launch_flat: the registers of six are not needed)
 #endif
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
                   // (a buffer load: its 32-bit byte offset is the whole address computation; nwords = 0 for a
                   //  look-up nobody needs sends it to word 0; floor(h * 4n / 2^32) & ~3 = 4 * floor(h * n / 2^32))
                   const uint32_t nb = (byte & (3u << (2 * u))) ? filter_bytes : 0u;
-                  word[u] = __builtin_amdgcn_raw_buffer_load_b32(filter_rsrc, __umulhi(h2, nb) & ~3u, 0, 0);
+                  word[u] = __builtin_amdgcn_raw_buffer_load_b32(filter_rsrc, __umulhi(h2, nb) & ~3u, 0, GF_FILTER_AUX);
                 }
                 uint32_t fail2 = 0;  // bit 2u: the filter rules out look-up u's 14-mer
 #pragma unroll
