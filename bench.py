@@ -401,10 +401,10 @@ def roofline_object(args, cfg, n, L, kern_ms_avg, stage_ms):
     measured = traffic / (kern_ms_avg * 1e-3) / 1e9 if traffic else None
     return {
         "bound": "hbm",
-        "binding_resource": "not HBM streaming (the pass moves a third of the algorithmic bytes): each tile's chain of "
-                            "dependent look-ups (seed filter, bucket, filter rounds, genes) at the latencies of a loaded "
-                            "memory system; neither VALU issue (-9 % instructions: -1 % time), occupancy (4..8 blocks per "
-                            "CU: flat) nor the L2's look-up rate (56 % of 269 G/s) is saturated (DESIGN.md §5)",
+        "binding_resource": "the XCDs' L2 tag pipelines, not HBM streaming (the pass moves a third of the algorithmic "
+                            "bytes): ~460 M L2 tag operations per pass (244 M hits, 75 M misses with their fills, writes) = "
+                            "over 80 % of one per channel and clock; with every other CU masked off the kernel takes the "
+                            "same time, with half the XCDs twice as long (DESIGN.md §5)",
         "kernel": {0: "gf_map_reads_device = 4 kernels: gf_k_seedverify_stream + gf_k_probe_filter + "
                       "gf_k_probe_buckets + gf_k_map_reads_list; achieved uses their summed duration",
                    1: "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
