@@ -189,6 +189,55 @@ int main() {
     EXPECT(c == P.counts);
   }
   gf_index_free(ix);
+  {
+    // multi-CSV mode runs its CSVs as concurrent jobs, each with an index of its own (fusion_scan.rs:103-110):
+    // T threads build, map and free their own indexes side by side, three rounds each (the freed blocks of one
+    // round are the next round's — and the other threads' — allocations); every thread's statistics and results
+    // equal those of the same gene set built alone
+    std::vector<std::vector<std::string>> sets(T);
+    std::vector<gf_index_info> want(T);
+    std::vector<std::vector<int32_t>> want_counts(T);
+    const Pack& P = packs[0];
+    auto build = [&](int t, gf_index** out) {
+      std::vector<const char*> p2;
+      std::vector<int64_t> l2;
+      for (auto& s : sets[t]) { p2.push_back(s.data()); l2.push_back((int64_t)s.size()); }
+      return gf_index_build(p2.data(), l2.data(), (int32_t)p2.size(), nullptr, out);
+    };
+    for (int t = 0; t < T; ++t) {
+      for (int c = 0; c < 2 + t % 3; ++c) sets[t].push_back(c == 0 ? genes[t % G] : rand_seq(g, 5000 + 3000 * t));
+      sets[t].push_back(sets[t][0].substr(100, 400));  // repeats: the one-pass build's side list is in use
+      gf_index* one = nullptr;
+      EXPECT(build(t, &one) == GF_OK);
+      EXPECT(gf_index_info_get(one, &want[t]) == GF_OK);
+      want_counts[t].assign(P.n(), 0);
+      std::vector<gf_seqmatch> m(2 * (size_t)P.n());
+      EXPECT(gf_map_reads(one, P.bases.data(), P.offsets.data(), P.n(), want_counts[t].data(), m.data()) == GF_OK);
+      gf_index_free(one);
+    }
+    std::atomic<int> bad2{0};
+    std::vector<std::thread> th2;
+    for (int t = 0; t < T; ++t)
+      th2.emplace_back([&, t] {
+        for (int rep = 0; rep < 3; ++rep) {
+          gf_index* mine = nullptr;
+          if (build(t, &mine) != GF_OK) { bad2++; return; }
+          gf_index_info got;
+          std::vector<int32_t> c(P.n());
+          std::vector<gf_seqmatch> m(2 * (size_t)P.n());
+          if (gf_index_info_get(mine, &got) != GF_OK || got.n_keys != want[t].n_keys || got.n_sites != want[t].n_sites ||
+              got.n_unique != want[t].n_unique || got.n_dupe_keys != want[t].n_dupe_keys ||
+              got.n_high_keys != want[t].n_high_keys || got.n_dupe_sites != want[t].n_dupe_sites)
+            bad2++;
+          if (gf_map_reads(mine, P.bases.data(), P.offsets.data(), P.n(), c.data(), m.data()) != GF_OK || c != want_counts[t])
+            bad2++;
+          gf_index_free(mine);
+        }
+      });
+    for (auto& x : th2) x.join();
+    EXPECT(bad2.load() == 0);
+    printf("concurrent index builds: %d threads x 3 rounds ok\n", T);
+  }
   printf("OK\n");
   return 0;
 }
