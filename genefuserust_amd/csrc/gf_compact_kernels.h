@@ -63,68 +63,98 @@ struct GfScanJob {
 };
 struct GfScanJobs { GfScanJob j[2]; };
 
-__global__ __launch_bounds__(1024) void gf_k_compact_scan(GfScanJobs jobs, int64_t ntiles) {
-  constexpr int ROWS = 16;
-  const uint32_t* __restrict__ tile_counts = jobs.j[blockIdx.x].tile_counts;
-  int64_t* __restrict__ tile_offsets = jobs.j[blockIdx.x].tile_offsets;
-  int64_t* __restrict__ d_total = jobs.j[blockIdx.x].d_total;
-  __shared__ long long s_w[ROWS * 16];  // [row][wavefront]: sums, then their exclusive prefix
-  __shared__ long long s_round;
+#define GF_SCAN_ROWS 16
+#define GF_SCAN_ROUND (1024 * GF_SCAN_ROWS)  // totals per round of a block
+
+// one round: totals b0 .. b0 + GF_SCAN_ROUND - 1 of a 1024-thread block; offsets = run + exclusive prefix; returns
+// the round's sum (the same in every thread).  s_w: GF_SCAN_ROWS * 16 + 1 long longs of LDS.
+__device__ __forceinline__ long long gf_scan_round(const uint32_t* __restrict__ tile_counts, int64_t ntiles, int64_t b0,
+                                                   long long run, int64_t* __restrict__ tile_offsets, long long* s_w) {
+  constexpr int ROWS = GF_SCAN_ROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long long run = 0;  // sum of all earlier rounds (the same in every thread)
-  for (int64_t b0 = 0; b0 < ntiles; b0 += 1024 * ROWS) {
-    uint32_t v[ROWS];
-    long long x[ROWS];
+  uint32_t v[ROWS];
+  long long x[ROWS];
 #pragma unroll
-    for (int k = 0; k < ROWS; ++k) {
-      const int64_t e = b0 + (int64_t)k * 1024 + threadIdx.x;
-      v[k] = e < ntiles ? tile_counts[e] : 0u;
-    }
+  for (int k = 0; k < ROWS; ++k) {
+    const int64_t e = b0 + (int64_t)k * 1024 + threadIdx.x;
+    v[k] = e < ntiles ? tile_counts[e] : 0u;
+  }
 #pragma unroll
-    for (int k = 0; k < ROWS; ++k) {
-      long long y = v[k];  // inclusive scan inside the wavefront
-      if (b0 + (int64_t)k * 1024 < ntiles) {  // (the same for the whole block: rows past the end hold zeros)
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const long long z = __shfl_up(y, o);
-          if (lane >= o) y += z;
-        }
-      }
-      x[k] = y;
-      if (lane == 63) s_w[k * 16 + wave] = y;
-    }
-    __syncthreads();
-    if (wave == 0) {  // 256 sums, four per lane, in (row, wavefront) order
-      long long a[4], mine = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = s_w[4 * lane + i];
-        mine += a[i];
-      }
-      long long y = mine;
+  for (int k = 0; k < ROWS; ++k) {
+    long long y = v[k];  // inclusive scan inside the wavefront
+    if (b0 + (int64_t)k * 1024 < ntiles) {  // (the same for the whole block: rows past the end hold zeros)
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const long long z = __shfl_up(y, o);
         if (lane >= o) y += z;
       }
-      long long pos = y - mine;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s_w[4 * lane + i] = pos;
-        pos += a[i];
-      }
-      if (lane == 63) s_round = y;
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < ROWS; ++k) {
-      const int64_t e = b0 + (int64_t)k * 1024 + threadIdx.x;
-      if (e < ntiles) tile_offsets[e] = run + s_w[k * 16 + wave] + x[k] - (long long)v[k];
-    }
-    run += s_round;
-    __syncthreads();  // s_w / s_round are rewritten in the next round
+    x[k] = y;
+    if (lane == 63) s_w[k * 16 + wave] = y;
   }
+  __syncthreads();
+  if (wave == 0) {  // 256 sums, four per lane, in (row, wavefront) order
+    long long a[4], mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = s_w[4 * lane + i];
+      mine += a[i];
+    }
+    long long y = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long z = __shfl_up(y, o);
+      if (lane >= o) y += z;
+    }
+    long long pos = y - mine;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s_w[4 * lane + i] = pos;
+      pos += a[i];
+    }
+    if (lane == 63) s_w[ROWS * 16] = y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < ROWS; ++k) {
+    const int64_t e = b0 + (int64_t)k * 1024 + threadIdx.x;
+    if (e < ntiles) tile_offsets[e] = run + s_w[k * 16 + wave] + x[k] - (long long)v[k];
+  }
+  const long long total = s_w[ROWS * 16];
+  __syncthreads();  // s_w is rewritten in the next round
+  return total;
+}
+
+__global__ __launch_bounds__(1024) void gf_k_compact_scan(GfScanJobs jobs, int64_t ntiles) {
+  const uint32_t* __restrict__ tile_counts = jobs.j[blockIdx.x].tile_counts;
+  int64_t* __restrict__ tile_offsets = jobs.j[blockIdx.x].tile_offsets;
+  int64_t* __restrict__ d_total = jobs.j[blockIdx.x].d_total;
+  __shared__ long long s_w[GF_SCAN_ROWS * 16 + 1];  // [row][wavefront]: sums, then their exclusive prefix; the total
+  long long run = 0;  // sum of all earlier rounds (the same in every thread)
+  for (int64_t b0 = 0; b0 < ntiles; b0 += GF_SCAN_ROUND) run += gf_scan_round(tile_counts, ntiles, b0, run, tile_offsets, s_w);
   if (threadIdx.x == 0) *d_total = run;
+}
+
+// Scans of hundreds of thousands of totals (the newline counts of a FASTQ text: one per 16 KB) in three launches
+// instead of dozens of dependent rounds of one block: block b scans round b on its own and leaves the round's sum,
+// gf_k_compact_scan scans those sums, gf_k_compact_scan_add adds a round's base to its offsets.
+__global__ __launch_bounds__(1024) void gf_k_compact_scan_rounds(const uint32_t* __restrict__ tile_counts, int64_t ntiles,
+                                                                 int64_t* __restrict__ tile_offsets,
+                                                                 uint32_t* __restrict__ round_sums) {
+  __shared__ long long s_w[GF_SCAN_ROWS * 16 + 1];
+  const long long t = gf_scan_round(tile_counts, ntiles, (int64_t)blockIdx.x * GF_SCAN_ROUND, 0, tile_offsets, s_w);
+  if (threadIdx.x == 0) round_sums[blockIdx.x] = (uint32_t)t;  // (the caller's totals keep a round's sum below 2^32)
+}
+
+__global__ __launch_bounds__(1024) void gf_k_compact_scan_add(int64_t* __restrict__ tile_offsets, int64_t ntiles,
+                                                              const int64_t* __restrict__ round_offsets) {
+  const long long base = round_offsets[blockIdx.x];
+  if (base == 0) return;
+#pragma unroll
+  for (int k = 0; k < GF_SCAN_ROWS; ++k) {
+    const int64_t e = (int64_t)blockIdx.x * GF_SCAN_ROUND + (int64_t)k * 1024 + threadIdx.x;
+    if (e < ntiles) tile_offsets[e] += base;
+  }
 }
 
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_compact_write(

@@ -261,6 +261,21 @@ static void launch_scan(hipStream_t st, int64_t ntiles, const uint32_t* c0, int6
   hipLaunchKernelGGL(gf_k_compact_scan, dim3(c1 ? 2 : 1), dim3(1024), 0, st, J, ntiles);
 }
 
+// the same for very many totals, with scratch for the rounds' sums (uint32 per round) and bases (int64 per round):
+// every total must be small enough for a round's 16 384 of them to sum below 2^32
+static inline int64_t scan_rounds(int64_t ntiles) { return (ntiles + GF_SCAN_ROUND - 1) / GF_SCAN_ROUND; }
+static void launch_scan_big(hipStream_t st, int64_t ntiles, const uint32_t* c0, int64_t* o0, int64_t* t0, uint32_t* round_sums,
+                            int64_t* round_offsets) {
+  const int64_t nr = scan_rounds(ntiles);
+  if (nr <= 2) {
+    launch_scan(st, ntiles, c0, o0, t0);
+    return;
+  }
+  hipLaunchKernelGGL(gf_k_compact_scan_rounds, dim3((unsigned)nr), dim3(1024), 0, st, c0, ntiles, o0, round_sums);
+  launch_scan(st, nr, round_sums, round_offsets, t0);
+  hipLaunchKernelGGL(gf_k_compact_scan_add, dim3((unsigned)nr), dim3(1024), 0, st, o0, ntiles, (const int64_t*)round_offsets);
+}
+
 static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** out, bool pair = false) {
   Workspace& W = ws_pool(pair).ws[WsKey{mix->device, st}];  // caller holds the pool's mutex
   if (W.bytes < need) {
@@ -1586,9 +1601,11 @@ static inline int64_t fq_tile_arrays_bytes(int64_t n_bytes) {
 }
 static inline int64_t fq_text_tiles(int64_t n_bytes) { return (n_bytes + GF_FQ_TILE - 1) / GF_FQ_TILE; }
 
+static inline int64_t fq_masks_bytes(int64_t n_bytes) { return fq_text_tiles(n_bytes) * (int64_t)(GF_CTHREADS * sizeof(uint64_t)); }
 int64_t gf_fastq_workspace_bytes(int64_t n_bytes) {
   if (n_bytes < 0) return 0;
-  return fq_tile_arrays_bytes(n_bytes) + fq_text_tiles(n_bytes) * (int64_t)(GF_CTHREADS * sizeof(uint64_t)) + 16;
+  // tile arrays | newline masks | the scan's round sums and bases (launch_scan_big)
+  return fq_tile_arrays_bytes(n_bytes) + fq_masks_bytes(n_bytes) + (scan_rounds(fq_text_tiles(n_bytes)) + 2) * 16 + 32;
 }
 
 int gf_fastq_index_device(const gf_index* idx, const void* d_text, int64_t n_bytes, void* d_nl_pos, int64_t cap_lines,
@@ -1609,7 +1626,11 @@ int gf_fastq_index_device(const gf_index* idx, const void* d_text, int64_t n_byt
                        tile_counts, masks);
     GF_HIP(hipGetLastError());
   }
-  launch_scan(st, ntiles, tile_counts, tile_offsets, n_lines + 1);
+  {
+    int64_t* round_offsets = (int64_t*)(((uintptr_t)masks + (size_t)fq_masks_bytes(n_bytes) + 15) & ~(uintptr_t)15);
+    uint32_t* round_sums = (uint32_t*)(round_offsets + scan_rounds(ntiles) + 1);
+    launch_scan_big(st, ntiles, tile_counts, tile_offsets, n_lines + 1, round_sums, round_offsets);  // (<= 16 384 newlines per tile)
+  }
   GF_HIP(hipGetLastError());
   if (ntiles > 0) {
     hipLaunchKernelGGL(gf_k_fq_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text, n_bytes,
