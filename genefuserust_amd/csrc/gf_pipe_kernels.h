@@ -482,6 +482,59 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 #pragma unroll
           for (int k = 0; k < NT; ++k) pp[k] = 0;
 #ifndef GF_SV_NO_INLINE_FILTER
+#ifndef GF_FILTER_ALLPAIRS
+          // r03, reads of up to 160 bases: HALF the look-ups, and the bound of gf_table.h (gf_vote_bound_pairs)
+          // in place of "fewer than 20 windows left".  Round 0 asks the even pairs of windows (0,1), (4,5),
+          // (8,9) .. — the seeds' pairs, already answered, are among them — which leaves the odd pairs standing,
+          // two windows with two ruled-out ones either side: a diagonal then gets at most 2 votes per 12 windows,
+          // 12 for a 150-base read where 20 are needed, and a false positive of the filter adds 3.  A read the
+          // bound does not stop (three false positives or more, or windows that really are in the table) asks
+          // the odd pairs in round 1 and meets the bound again with everything known.  13 + 4 look-ups instead of
+          // 28 + 4 for a background read, and these look-ups are the kernel's bound.
+          if (PW == 10 && K == GF_NONE_LIN && T.bloom_in_l2 == 2) {
+            filt_done = true;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) pp[k] = cwb[k];
+            bool alive = true;
+#pragma unroll 1
+            for (uint32_t rnd = 0; rnd < 2; ++rnd) {
+              if (alive) {
+                uint32_t wlo = gf_cut_pk(s_pk, w0, sh, 0);
+#pragma unroll
+                for (int j = 0; j < PW; ++j) {
+                  const uint32_t whi = j + 1 < PW ? gf_cut_pk(s_pk, w0, sh, j + 1) : 0u;
+                  const uint32_t byte = (pp[j >> 2] >> (8 * (j & 3))) & 0xFFu;  // this word's 8 windows
+                  uint32_t word[2], bits[2];
+#pragma unroll
+                  for (int t = 0; t < 2; ++t) {
+                    // pair u = 2t + rnd of the word: windows 8j+2u, 8j+2u+1 share the 14-mer at bases 16j + 4u+2 ..
+                    const uint32_t s14 = __builtin_amdgcn_alignbit(whi, wlo, 16u * (uint32_t)t + 8u * rnd + 4u) & 0x0FFFFFFFu;
+                    const uint32_t h2 = GF_BLOOM_HASH((s14));
+                    bits[t] = GF_BLOOM_BITS(h2);
+                    const uint32_t nb = (byte & (3u << (4 * t + 2 * rnd))) ? filter_bytes : 0u;  // nobody to ask for: word 0
+                    word[t] = __builtin_amdgcn_raw_buffer_load_b32(filter_rsrc, __umulhi(h2, nb) & ~3u, 0, GF_FILTER_AUX);
+                  }
+                  uint32_t fail2 = 0;  // bit 2u: the filter rules out pair u's 14-mer
+#pragma unroll
+                  for (int t = 0; t < 2; ++t) {
+                    const uint32_t d = bits[t] & ~word[t];
+                    uint32_t f;
+                    asm("v_min_u32 %0, %1, 1" : "=v"(f) : "v"(d));
+                    fail2 |= f << (4 * t);
+                  }
+                  fail2 <<= 2 * rnd;
+                  pp[j >> 2] &= ~((fail2 | (fail2 << 1)) << (8 * (j & 3)));
+                  wlo = whi;
+                }
+                uint32_t x[NT];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) x[k] = (pp[k] | (pp[k] >> 1)) & 0x55555555u;
+                alive = gf_vote_bound_pairs<4 * PW - 3>(x) >= GF_MAJOR_KEYS / 2;
+              }
+            }
+            filt_dead = !alive;
+          } else
+#endif
           if (K == GF_NONE_LIN && T.bloom_in_l2 == 2) {
             filt_done = true;
             int npos = 0, rem = nvalid;

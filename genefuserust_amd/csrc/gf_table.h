@@ -156,6 +156,45 @@ GF_HD uint32_t gf_key_from_ref_kmer(uint32_t k) {
   return (k >> 16) | (k << 16);
 }
 
+// ---- how many first-pass votes ONE diagonal can still collect (r03) ----
+// indexer.rs:275-321 gives a diagonal one vote per stride-2 window whose key has a site on it.  In site-code
+// space (gdu, above) a vote of window w (read base 2w) for diagonal K says: read[2w .. 2w+16) == G[K+2w .. K+2w+16)
+// and K+2w is an indexed site.  Two windows u < v that vote for the same K with v - u <= 7 (their bases overlap
+// or touch with at most 14 between the starts) lie on ONE strand of one gene — a reverse-strand site and a
+// forward site of a contig are at least 16 codes apart, contigs 4096 — so read[2u .. 2v+16) equals G there and
+// every site code between K+2u and K+2v is an indexed site with exactly the read's window on it: the key of
+// EVERY window between u and v is in the table (indexer.rs:188-240 files a site for every valid window of a
+// strand but the last).  Contrapositive, which is what the presence filter can use: two voters of one diagonal
+// with a window between them whose key is provably absent are at least 8 windows apart.  So with `can` = the
+// windows not yet ruled out, a diagonal's voters V satisfy: u, v in V, v - u <= 7  =>  all of u..v in `can`;
+// the largest such V is an upper bound of count1 (indexer.rs:336-346), far below popcount(can) when the
+// windows ruled out are spread evenly: 2 of every 4 windows ruled out leave at most 2 votes per 12 windows.
+//
+// Pairs: the filter answers for windows 2P, 2P+1 together (they share a 14-mer), so the bound is computed on
+// pairs — pair P counts as standing when either of its windows does (more windows can only raise the bound).
+// h[P] = most voters of a set whose last voter is window 2P+1, F[P] = max h[0..P]:
+//   h[P] = 2 + max(h[P-1], F[P-5], h[P-4] - 1)   (P standing; else 0)
+// (h[P-1]: the same run of standing windows; F[P-5]: a voter at or below window 2P-9, 8 or more below window 2P;
+//  h[P-4] - 1: window 2P-8 last, i.e. pair P-4 without its upper window.)  tests/test_vote_bound.py checks the
+// recurrence against exhaustive search and the statement itself against the oracle's vote lists.
+// x[k] bit 2q = pair 16k + q standing (bits at the even positions, as (w | w >> 1) & 0x55555555 leaves them).
+template <int NPAIRS>
+GF_HD int gf_vote_bound_pairs(const uint32_t* x) {
+  int h1 = 0, h2 = 0, h3 = 0, h4 = 0;          // h[P-1] .. h[P-4]
+  int f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;  // F[P-1] .. F[P-5]
+#pragma unroll
+  for (int P = 0; P < NPAIRS; ++P) {
+    const int standing = -(int)((x[P >> 4] >> (2 * (P & 15))) & 1u);  // 0 or ~0
+    int t = h1 > f5 ? h1 : f5;
+    t = t > h4 - 1 ? t : h4 - 1;
+    const int h = (t + 2) & standing;
+    const int f = f1 > h ? f1 : h;
+    h4 = h3; h3 = h2; h2 = h1; h1 = h;
+    f5 = f4; f4 = f3; f3 = f2; f2 = f1; f1 = f;
+  }
+  return f1;
+}
+
 // 4 ASCII bases in one little-endian dword -> 8 bits of codes (first base in the
 // low bits) and 4 invalid flags.  Valid bases are exactly 'A','C','G','T'
 // (indexer.rs:825-841: anything else, lower case included, voids the window).

@@ -16,7 +16,11 @@ BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity
 PMC_SETS=${PMC_SETS:-all}
 echo "== kernel trace ==" 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.log 2>&1 || { echo trace failed; tail -20 $OUT/trace_bench.log; exit 1; }
-SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum")
+# (r03: TCC_BUBBLE = the 128-byte read requests FETCH_SIZE's gfx950 formula relies on; the _DRAM_32B counter
+#  tallies a 64-byte request as 2 and a 128-byte one as 4, i.e. bytes / 32 whatever the request size)
+SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum"
+      "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_32B_sum" "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum"
+      "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum")
 if [ "$PMC_SETS" = "all" ]; then
   SETS+=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE")
 fi
