@@ -19,8 +19,10 @@ all-gather of the per-rank hit lists (the path's only exchange).  --config picks
                (genefuserust_amd/multi_csv.py: CSV k -> rank k % N, no collective when there are
                at least N CSVs).  value = (reads x CSVs) / s, index rebuilds inside the timed region.
 
-One process per GPU, launched by torch.distributed.run for N > 1.  Rank 0 prints ONE JSON
-line (see DESIGN.md "Measurement").
+One process per GPU.  `python bench.py --gpus N` without WORLD_SIZE in the environment starts its N ranks
+itself (a child `python -m torch.distributed.run ... bench.py <same arguments>`, before this process touches the
+GPU) and relays rank 0's line and the child's exit code; under torch.distributed.run it is a rank.  Rank 0 prints
+ONE JSON line (see DESIGN.md "Measurement").
 """
 import argparse
 import json
@@ -44,8 +46,13 @@ CONFIGS = {
 SHAPE_TEXT = {"IDX-D": "druggable.hg38-shaped: first 32 gene spans of testdata/cancer.csv",
               "IDX-C": "cancer.hg38-shaped: all 136 gene spans of testdata/cancer.csv",
               "IDX-T": "the 4 gene spans of testdata/fusions.csv"}
-READS_TEXT = ("reads are independent draws (40 % background / 59.9 % single-gene / 0.1 % junction for PANEL), half of "
-              "them reverse-complemented — mate-like orientation, not N(300,30) fragment pairs: the metric is per read")
+READS_TEXT = {
+    "pairs": "read pairs per SURVEY.md 8(d): fragments N(300,30) clipped to [150,500] (40 % background / 59.9 % one gene / "
+             "0.1 % across a junction for PANEL), R1 = the fragment's first bases, R2 = the reverse complement of its far "
+             "end, interleaved R1,R2,R1,R2 as a pair-end scan presents them; value counts reads",
+    "independent": "reads are independent draws (40 % background / 59.9 % single-gene / 0.1 % junction for PANEL), half of "
+                   "them reverse-complemented — mate-like orientation, not N(300,30) fragment pairs",
+}
 
 
 def _lib_compact_ws_bytes(n: int) -> int:
@@ -99,6 +106,23 @@ def traffic_entry(shape: str, n: int, L: int):
         return None
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` run plainly: start the N ranks as a CHILD torch.distributed.run (this process has not
+    initialised the GPU and never will), let rank 0's JSON line through on our stdout, return the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,10 +142,18 @@ def main() -> None:
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-packed", action="store_true", help="config 4: map the ASCII reads per CSV instead of packing them once")
+    ap.add_argument("--reads", default="pairs", choices=["pairs", "independent"],
+                    help="pairs (default): synth.make_pair_reads, SURVEY.md 8(d); independent: synth.make_reads (r01/r02's workload)")
+    ap.add_argument("--profile-mode", action="store_true", help="only warm-up + timed passes (for rocprofv3 runs): no CPU baseline, "
+                    "parity, h2d, packed or per-stage extras")
     ap.add_argument("--calib", action="store_true", help="after the timed steps, launch the counter-calibration kernels of "
                     "tools/gf_calib.hip on the batch's own bases (known byte counts in the same rocprofv3 pass)")
     ap.add_argument("--variant", type=int, default=0, help="first pass: 0 flat pipeline (default), 1 wave-per-read probe-all, 2 wave-per-read seed+verify")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))   # (nothing has touched the GPU yet)
+    if args.profile_mode:
+        args.no_cpu_baseline = args.no_parity = args.no_h2d = True
     cfg = dict(CONFIGS[args.config])
     if args.shape:
         cfg["shape"] = args.shape
@@ -143,8 +175,8 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or plainly "
+                         "(bench.py then starts its ranks itself)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (gfmatch has no CPU fallback)")
     # GF_BENCH_REHEARSAL=1: every rank uses cuda:0 and the collective runs on gloo — only to
@@ -188,25 +220,20 @@ def main() -> None:
     t_index = time.time() - t0
     ix.set_map_variant(args.variant)
     info = ix.info()
-    reads = synth.make_reads(genes, n, read_len=L, mix=args.mix, seed=seed + 1000 * rank, device=str(dev))
+    if args.reads == "pairs" and n % 2 == 0:
+        reads = synth.make_pair_reads(genes, n // 2, read_len=L, mix=args.mix, seed=seed + 1000 * rank, device=str(dev))
+    else:
+        args.reads = "independent"
+        reads = synth.make_reads(genes, n, read_len=L, mix=args.mix, seed=seed + 1000 * rank, device=str(dev))
     counts = torch.empty(n, dtype=torch.uint8, device=dev)
     matches = torch.empty((n, 2, 4), dtype=torch.int32, device=dev)
     read_id_base = lo
     stream = torch.cuda.current_stream(dev)
 
-    # N > 1: the per-rank hit lists are merged by one asynchronous all-gather per step
-    # (genefuserust_amd/dist.py::HitExchange): fixed-capacity blocks, no host round trip, so the
-    # exchange of step k overlaps the mapping of step k+1; every step's merged list is finished
-    # (waited for and packed on the device) inside the timed region.
-    exch = None
-    exchange_name = "none (single GPU)"
-    if world > 1:
-        if rehearsal or os.environ.get("GF_BENCH_PLAIN_ALLGATHER") == "1":
-            exchange_name = "allgather_hits (counts, then padded records; host round trip)"
-        else:
-            from genefuserust_amd.dist import HitExchange
-            exch = HitExchange(cap=max(4096, n // 512), device=dev)
-            exchange_name = "HitExchange (one asynchronous fixed-capacity all-gather, pipelined one step deep)"
+    # N > 1: the per-rank hit lists are merged by ONE all-gather per step through the C ABI
+    # (gf_allgather_hits_device, include/gfmatch.h: RCCL called by libgfmatch.so; genefuserust_amd/dist.py::RcclHitExchange
+    # drives it on a side stream): fixed-capacity blocks, no host round trip, so the exchange of step k overlaps the
+    # mapping of step k+1; every step's merged list is finished (waited for, packed on the device) inside the timed region.
     pending = []
     # the step's outputs are preallocated (two sets, alternating: the exchange of step k may still read set k
     # while step k+1 writes the other): nothing is allocated inside the timed region
@@ -214,6 +241,22 @@ def main() -> None:
     out_sets = [(torch.empty((max(n // 16, 1), 6), dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev),
                  torch.empty(cws, dtype=torch.uint8, device=dev)) for _ in range(2)]
     step_no = [0]
+    exch = None
+    exchange_name = "none (single GPU)"
+    if world > 1:
+        if rehearsal or os.environ.get("GF_BENCH_PLAIN_ALLGATHER") == "1":
+            exchange_name = "allgather_hits over torch.distributed (counts, then padded records; host round trip)"
+        else:
+            from genefuserust_amd.dist import RcclHitExchange
+            # capacity: twice the largest per-rank list of a first pass (the same on every rank); a rank over it is
+            # reported by the exchange and fails the run — never cut silently
+            ix.map_reads_device(reads.bases, reads.offsets, L, counts, matches)
+            _, nh = ix.compact_hits_device(counts, matches, n, read_id_base=read_id_base, cap=n // 16, out=out_sets[0])
+            mx = nh.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            exch = RcclHitExchange(cap=min(max(4096, 2 * int(mx.item())), max(n // 16, 1)), device=dev)
+            exchange_name = ("gf_allgather_hits_device: one ncclAllGather of %d-record blocks through the C ABI, on a side "
+                             "stream, pipelined one step deep" % exch.cap)
 
     def step(ev=None):
         if ev is not None:
@@ -239,19 +282,9 @@ def main() -> None:
             out = exch.finish(pending.pop(0))
         return out
 
-    try:
-        for _ in range(args.warmup):
-            step()
-        drain()
-    except Exception as e:  # noqa: BLE001 — the exchange failing the same way on every rank: use the plain path
-        if exch is None:
-            raise
-        print("HitExchange failed (%s): falling back to allgather_hits" % e, file=sys.stderr)
-        exch = None
-        exchange_name = "allgather_hits (FALLBACK: HitExchange raised %s in warm-up)" % type(e).__name__
-        pending.clear()
-        for _ in range(args.warmup):
-            step()
+    for _ in range(args.warmup):   # (a failing exchange fails the run: no silent fall-back to a slower path)
+        step()
+    drain()
     barrier()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -287,7 +320,7 @@ def main() -> None:
     # per-kernel durations of the flat pipeline (HIP events inside the library, launch stream),
     # taken on extra steps outside the timed region
     stage_ms = None
-    if args.variant == 0:
+    if args.variant == 0 and not args.profile_mode:
         ix.set_profiling(True)
         acc = [0.0, 0.0, 0.0, 0.0]
         reps = 5
@@ -302,7 +335,7 @@ def main() -> None:
     # the packed hand-over (gf_map_reads_packed_device), outside the timed region: the same reads in the
     # kernels' own 2-bit form — what a device-side producer or a host that maps a read set repeatedly hands over
     packed_ms = None
-    if args.variant == 0 and rank == 0:
+    if args.variant == 0 and rank == 0 and not args.profile_mode:
         t_ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         t_ev[0].record(stream)
         pk, iv = ix.pack_bases_device(reads.bases)
@@ -323,9 +356,11 @@ def main() -> None:
     value = total_reads * args.steps / elapsed
     if world == 1:
         n_hits_total = int(out[1].item())
-    elif isinstance(out, tuple):  # HitExchange: (merged, total, overflow)
-        assert not bool(out[2].item()), "hit exchange capacity exceeded: raise HitExchange cap"
-        n_hits_total = int(out[1].item())
+    elif isinstance(out, tuple):  # RcclHitExchange: (merged, totals = [records, overflow flag, per-rank counts ..])
+        tot = out[1].cpu().tolist()
+        if tot[1]:
+            raise SystemExit("hit exchange over capacity: per-rank counts %s, cap %d" % (tot[2:], exch.cap))
+        n_hits_total = int(tot[0])
     else:
         n_hits_total = int(out.shape[0])
 
@@ -347,7 +382,7 @@ def main() -> None:
                         % (cfg["name"] if not (args.shape or args.pairs) else cfg["name"] + " (overridden)",
                            total_reads // 2, L, total_reads,
                            "in total, %d reads on each of %d ranks" % (n, world) if world > 1 else "on one GPU",
-                           cfg["shape"], SHAPE_TEXT[cfg["shape"]], info["total_bp"], args.mix, READS_TEXT),
+                           cfg["shape"], SHAPE_TEXT[cfg["shape"]], info["total_bp"], args.mix, READS_TEXT[args.reads]),
             "baseline_config": args.config,
             "reads_per_gpu_per_step": n,
             "read_len": L,
@@ -364,8 +399,28 @@ def main() -> None:
     if gene_kw:
         result["config"]["gene_synthesis"] = gene_kw
 
+    # PCIe-inclusive rate, every rank through its own link at the same time (never `value`): what N GPUs buy a HOST —
+    # the device-resident rate of one GPU is already 20x what one link feeds, the links are what scales
+    h2d = None
+    if not args.no_h2d:
+        barrier()
+        try:
+            h2d = h2d_inclusive(ix, reads, n, L)
+        except Exception as e:  # noqa: BLE001 — a reported extra, never the value
+            h2d = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world > 1:
+            v = torch.tensor([h2d.get("reads_per_s", 0.0), h2d.get("host_GBps", 0.0)], dtype=torch.float64,
+                             device="cpu" if rehearsal else dev)
+            allv = [torch.zeros_like(v) for _ in range(world)]
+            dist.all_gather(allv, v)
+            per = [[float(x) for x in t.cpu()] for t in allv]
+            h2d = dict(h2d, per_rank_reads_per_s=[p[0] for p in per], reads_per_s_all_ranks=sum(p[0] for p in per),
+                       host_GBps_all_ranks=sum(p[1] for p in per),
+                       note="every rank streams its own 8 M-read sample from pinned host memory through its own link, concurrently")
     if rank == 0:
         result["roofline"] = roofline_object(args, cfg, n, L, kern_ms_avg, stage_ms)
+        if h2d is not None:
+            result["h2d_inclusive"] = h2d
         if packed_ms:
             packed_ms["kernel_reads_per_s"] = n / (packed_ms["map_ms"] * 1e-3)
             result["packed_input"] = packed_ms
@@ -389,11 +444,6 @@ def main() -> None:
                 result["parity"] = {"checked_reads": ns, "bit_exact": ok, "reads_with_segments": int(nz.sum())}
             if want_cpu:
                 result["cpu_baseline"] = cpu_baseline(ox, reads, n, L, cores, args.cpu_seconds)
-        if world == 1 and not args.no_h2d:
-            try:
-                result["h2d_inclusive"] = h2d_inclusive(ix, reads, n, L)
-            except Exception as e:  # noqa: BLE001 — a reported extra, never the value
-                result["h2d_inclusive"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(result), flush=True)
 
     if world > 1:
@@ -401,42 +451,54 @@ def main() -> None:
         dist.destroy_process_group()
 
 
+COMPULSORY_BYTES_PER_READ = lambda L: L + 8 + 1   # its bases, its int64 offset, its count byte: what any design must move
+
+
 def roofline_object(args, cfg, n, L, kern_ms_avg, stage_ms):
-    """`achieved`/`frac` follow the contract: ALGORITHMIC bytes (706 B per 150-bp read, of
-    which 544 B are 'one 8-byte index slot per probe' that this design never fetches) over the summed
-    duration of the pass's kernels.  That is NOT the bandwidth the memory system delivers: `traffic`
-    (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/hbm_traffic.json) over the same time is
-    `measured_GBps` / `traffic_frac`, and that is the figure to read as "fraction of HBM peak in use"."""
+    """`frac` = bytes the L2s exchanged with the fabric per pass (rocprofv3 PMC, calibrated: profiles/hbm_traffic.json,
+    tools/make_traffic.py) / summed duration of the pass's kernels / 8 TB/s — what the memory system delivers.
+    `algorithmic_frac` is the contract's formula (706 B per 150-bp read, 544 B of them 'one 8-byte index
+    slot per probe' that this design never fetches) over the same time; `compulsory_frac` charges only a read's own
+    bytes.  When no counter measurement exists for the workload, `frac` falls back to the algorithmic figure and says so."""
+    secs = kern_ms_avg * 1e-3
     algo = algo_bytes_per_read(L) * n  # bytes per launch
-    achieved = algo / (kern_ms_avg * 1e-3) / 1e9
+    algo_gbps = algo / secs / 1e9
+    comp_gbps = COMPULSORY_BYTES_PER_READ(L) * n / secs / 1e9
     te = traffic_entry(cfg["shape"], n, L) if args.scale == 1.0 and args.mix == "PANEL" else None
     traffic = te["hbm_bytes_per_launch"] if te else None
-    measured = traffic / (kern_ms_avg * 1e-3) / 1e9 if traffic else None
+    measured = traffic / secs / 1e9 if traffic else None
+    achieved = measured if measured is not None else algo_gbps
     return {
-        "bound": "hbm",
-        "binding_resource": "the XCDs' L2 tag pipelines, not HBM streaming (the pass moves a third of the algorithmic "
-                            "bytes): ~460 M L2 tag operations per pass (244 M hits, 75 M misses with their fills, writes) = "
-                            "over 80 % of one per channel and clock; with every other CU masked off the kernel takes the "
-                            "same time, with half the XCDs twice as long (DESIGN.md §5)",
-        "kernel": {0: "gf_map_reads_device = 4 kernels: gf_k_seedverify_stream + gf_k_probe_filter + "
-                      "gf_k_probe_buckets + gf_k_map_reads_list; achieved uses their summed duration",
+        "bound": "l2_tag",
+        "binding_resource": "the XCDs' L2s, hits and misses adding up: seed+verify's time follows 4.8 ps per L2 hit (the presence "
+                            "filter's look-ups) + 14.8 ps per L2 miss (a 128-byte line over the fabric each: bases, buckets, genes, "
+                            "evicted filter lines) across filter sizes and read mixes; with every other CU masked off it takes the "
+                            "same time, with half the XCDs twice as long (DESIGN.md 5)",
+        "kernel": {0: "gf_map_reads_device = 4 kernels: gf_k_seedverify_stream (dominant) + gf_k_probe_filter + "
+                      "gf_k_probe_buckets + gf_k_map_reads_list; their summed duration",
                    1: "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
                    2: "gf_k_map_reads_short<4,1> (wave per read, seed+verify)"}[args.variant],
         "stage_ms": stage_ms,
         "achieved": achieved,
-        "algorithmic_GBps": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "frac_definition": "algorithmic bytes / kernel time / 8 TB/s (the contract's formula); see traffic_frac for measured bytes",
+        "frac_definition": ("measured: (32 B x TCC_EA0_RDREQ_DRAM_32B + WRITE_SIZE) per pass / kernel time / 8 TB/s"
+                            if measured is not None else
+                            "ALGORITHMIC (no counter measurement for this workload): 706 B per read / kernel time / 8 TB/s"),
         "traffic": traffic,
         "traffic_source": (te or {}).get("source"),
-        "measured_GBps": measured,
-        "traffic_frac": measured / HBM_PEAK_GBS if measured else None,
+        "traffic_read_bytes": (te or {}).get("read_bytes_per_launch"),
+        "traffic_write_bytes": (te or {}).get("write_bytes_per_launch"),
+        "algorithmic_GBps": algo_gbps,
+        "algorithmic_frac": algo_gbps / HBM_PEAK_GBS,
         "algorithmic_bytes_per_read": algo_bytes_per_read(L),
+        "compulsory_GBps": comp_gbps,
+        "compulsory_frac": comp_gbps / HBM_PEAK_GBS,
+        "compulsory_bytes_per_read": COMPULSORY_BYTES_PER_READ(L),
         "reads_per_launch": n,
         "kernel_ms_avg": kern_ms_avg,
-        "kernel_reads_per_s": n / (kern_ms_avg * 1e-3),
+        "kernel_reads_per_s": n / secs,
     }
 
 
@@ -534,8 +596,13 @@ def bench_multi_csv(args, cfg, world, rank, local_rank, dev, barrier, seed, gene
     # the resident reads: drawn from CSV 0's and CSV 1's genes (every rank holds the same set)
     base_sets = [synth.make_geneset(("IDX-C", "IDX-D")[k], scale=args.scale, seed=1000 + 37 * k, **gene_kw) for k in (0, 1)]
     half = n // 2
-    ra = synth.make_reads(base_sets[0], half, read_len=L, mix=args.mix, seed=seed, device=str(dev))
-    rb = synth.make_reads(base_sets[1], n - half, read_len=L, mix=args.mix, seed=seed + 1, device=str(dev))
+    if args.reads == "pairs" and half % 2 == 0 and (n - half) % 2 == 0:
+        ra = synth.make_pair_reads(base_sets[0], half // 2, read_len=L, mix=args.mix, seed=seed, device=str(dev))
+        rb = synth.make_pair_reads(base_sets[1], (n - half) // 2, read_len=L, mix=args.mix, seed=seed + 1, device=str(dev))
+    else:
+        args.reads = "independent"
+        ra = synth.make_reads(base_sets[0], half, read_len=L, mix=args.mix, seed=seed, device=str(dev))
+        rb = synth.make_reads(base_sets[1], n - half, read_len=L, mix=args.mix, seed=seed + 1, device=str(dev))
     bases = torch.cat([ra.bases, rb.bases])
     offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
     del ra, rb
@@ -617,7 +684,7 @@ def bench_multi_csv(args, cfg, world, rank, local_rank, dev, barrier, seed, gene
         "config": {
             "workload": "%s: %d resident %d-bp reads (%d pairs), %d fusion CSVs alternating IDX-C / IDX-D gene spans (own "
                         "seed each), index rebuilt per CSV inside the timed region; value counts a read once per CSV; %s"
-                        % (cfg["name"], n, L, n // 2, n_csv, READS_TEXT),
+                        % (cfg["name"], n, L, n // 2, n_csv, READS_TEXT[args.reads]),
             "baseline_config": 4, "reads_resident": n, "n_csv": n_csv, "read_len": L,
             "csvs_of_rank0": [j.csv for j in jobs],
             "reads_form": "ASCII" if args.no_packed else "packed once per step (gf_pack_bases_device), mapped per CSV with gf_map_reads_packed_device",
@@ -632,13 +699,27 @@ def bench_multi_csv(args, cfg, world, rank, local_rank, dev, barrier, seed, gene
     }
     if rank == 0:
         tot_build, tot_map = sum(build_ms), sum(map_ms)
+        algo_gbps = algo_bytes_per_read(L) * n * len(jobs) * args.steps / (tot_map * 1e-3) / 1e9 if tot_map else None
+        # counter-measured bytes of one whole step (every kernel: rebuilds, packing, mapping passes, compaction),
+        # profiles/hbm_traffic.json key config4_<reads>x<csvs>_<L>, over the step's wall time
+        te = None
+        try:
+            te = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("config4_%dx%d_%d" % (n, n_csv, L))
+        except Exception:
+            pass
+        step_s = elapsed / args.steps
+        traffic = te["hbm_bytes_per_launch"] if te and world == 1 and not args.no_packed else None
+        measured = traffic / step_s / 1e9 if traffic else None
         result["roofline"] = {
-            "bound": "hbm", "kernel": "index rebuild (K1) + mapping pass per CSV",
-            "achieved": algo_bytes_per_read(L) * n * len(jobs) * args.steps / (tot_map * 1e-3) / 1e9 if tot_map else None,
+            "bound": "l2_tag", "kernel": "one step = per CSV: index rebuild (K1) + mapping pass (4 kernels) + compaction; the reads packed once",
+            "achieved": measured if measured is not None else algo_gbps,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (algo_bytes_per_read(L) * n * len(jobs) * args.steps / (tot_map * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot_map else None,
-            "frac_definition": "algorithmic bytes of the mapping passes / their host-timed duration (includes compaction and one sync per CSV)",
-            "traffic": None,
+            "frac": (measured if measured is not None else algo_gbps) / HBM_PEAK_GBS if (measured or algo_gbps) else None,
+            "frac_definition": ("measured: (32 B x TCC_EA0_RDREQ_DRAM_32B + WRITE_SIZE) of every kernel of a step / the step's wall time / 8 TB/s"
+                                if measured is not None else
+                                "ALGORITHMIC (no counter measurement for this workload): 706 B per read and CSV / host-timed mapping time / 8 TB/s"),
+            "traffic": traffic, "traffic_source": (te or {}).get("source"),
+            "algorithmic_GBps": algo_gbps, "algorithmic_frac": algo_gbps / HBM_PEAK_GBS if algo_gbps else None,
             "share_of_step_in_index_rebuild": tot_build / (tot_build + tot_map) if tot_build + tot_map else None,
         }
         if not args.no_parity:

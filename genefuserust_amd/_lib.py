@@ -21,6 +21,8 @@ GF_ERR_HIP = -2
 GF_ERR_NO_DEVICE = -3
 GF_ERR_CAPACITY = -4
 GF_ERR_READ_TOO_LONG = -5
+GF_ERR_COMM = -6
+GF_COMM_ID_BYTES = 128
 GF_MAX_READ_LEN = 4096
 GF_COUNT_TOO_LONG = 255
 
@@ -185,6 +187,20 @@ def lib() -> C.CDLL:
     L.gf_host_free.restype = None
     L.gf_edit_distance.argtypes = [C.c_char_p, i64, C.c_char_p, i64]
     L.gf_edit_distance.restype = i64
+    L.gf_comm_unique_id.argtypes = [vp]
+    L.gf_comm_unique_id.restype = C.c_int
+    L.gf_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.gf_comm_init.restype = C.c_int
+    L.gf_comm_rank.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.gf_comm_rank.restype = C.c_int
+    L.gf_comm_free.argtypes = [vp]
+    L.gf_comm_free.restype = None
+    L.gf_allgather_workspace_bytes.argtypes = [i32, i64]
+    L.gf_allgather_workspace_bytes.restype = i64
+    L.gf_allgather_hits_device.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
+    L.gf_allgather_hits_device.restype = C.c_int
+    L.gf_pack_gathered_hits_device.argtypes = [vp, i32, i64, vp, vp, vp]
+    L.gf_pack_gathered_hits_device.restype = C.c_int
     L.gf_set_profiling.argtypes = [vp, i32]
     L.gf_set_profiling.restype = C.c_int
     L.gf_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]

@@ -304,7 +304,11 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {  // all of the tile's loads in flight together
           const uint32_t c = (uint32_t)lane + 64u * (uint32_t)k;
-#ifndef GF_STAGE_TEMPORAL  // streamed once: keep the bases out of the way of the table and the filter
+#if defined(GF_STAGE_AUX)  // experiments: the staging loads as buffer loads with explicit cache-policy bits (1 sc0, 2 nt, 16 sc1)
+          const __amdgpu_buffer_rsrc_t stage_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(chunks * 16u), 0x00020000);
+          const auto t = __builtin_amdgcn_raw_buffer_load_b128(stage_rsrc, 16u * (c < chunks ? c : chunks - 1), 0, GF_STAGE_AUX);
+          q[k] = make_uint4(t[0], t[1], t[2], t[3]);
+#elif !defined(GF_STAGE_TEMPORAL)  // streamed once: keep the bases out of the way of the table and the filter
           const gf_u32x4 t = __builtin_nontemporal_load((const gf_u32x4*)(src + (c < chunks ? c : chunks - 1)));
           q[k] = make_uint4(t.x, t.y, t.z, t.w);
 #else

@@ -4,6 +4,7 @@
 // kernels of gf_index_kernels.h / gf_map_kernels.h / gf_compact_kernels.h or
 // fails with an error code.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -21,6 +22,7 @@
 
 #include "../../include/gfmatch.h"
 #include "gf_compact_kernels.h"
+#include "gf_exchange_kernels.h"
 #include "gf_index_kernels.h"
 #include "gf_map_kernels.h"
 #include "gf_merge_kernels.h"
@@ -199,6 +201,7 @@ struct gf_index {
   bool have_events = false;
   bool recorded = false;
   uint8_t* d_gene_rev = nullptr;  // Fusion::is_reversed() per gene (gf_index_set_gene_reversed)
+  std::atomic<int> open_streams{0};  // gf_streams opened on this index and not closed yet
   // lanes of the host-buffer entry points (gf_map_reads, gf_map_read, gf_map_reads_hits): see HostLane
   std::vector<struct HostLane*> lanes;
   std::mutex lane_mu;
@@ -238,14 +241,42 @@ struct gf_index {
 // stream cannot interleave their kernels.  (Stream-ordered hipMallocAsync/hipFreeAsync was tried
 // first: on the legacy default stream a free issued right after the launches raced with the kernels.)
 // gf_index_trim releases a device's workspaces; nothing is freed at process exit.
-struct Workspace { void* base = nullptr; size_t bytes = 0; };
+struct Workspace {
+  void* base = nullptr;
+  size_t bytes = 0;
+  std::mutex mu;  // this entry's buffers and the launch sequences that use them (one stream's calls stay in order)
+};
 struct WsKey {
   int device; hipStream_t st;
   bool operator<(const WsKey& o) const { return device != o.device ? device < o.device : st < o.st; }
 };
+// The pool's own mutex guards the map only; growing a workspace (stream sync, hipFree, hipMalloc) and queueing
+// a call's launches happen under the ENTRY's mutex, so callers on other streams and other GPUs are not held up
+// (one pool-wide mutex stalled every caller behind one thread's hipMalloc).
 struct WsPool {
-  std::mutex mu;  // the map, and the launch sequences that use its buffers
-  std::map<WsKey, Workspace> ws;
+  std::mutex mu;
+  std::map<WsKey, std::shared_ptr<Workspace>> ws;
+  std::shared_ptr<Workspace> entry(int device, hipStream_t st) {
+    std::lock_guard<std::mutex> g(mu);
+    auto& e = ws[WsKey{device, st}];
+    if (!e) e = std::make_shared<Workspace>();
+    return e;
+  }
+  // forget (and free) the workspace of a stream that is about to be destroyed; the caller has drained the stream
+  void drop(int device, hipStream_t st) {
+    std::shared_ptr<Workspace> e;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = ws.find(WsKey{device, st});
+      if (it == ws.end()) return;
+      e = it->second;
+      ws.erase(it);
+    }
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->base) (void)hipFree(e->base);
+    e->base = nullptr;
+    e->bytes = 0;
+  }
 };
 static WsPool& ws_pool(bool pair) {
   static WsPool* pools = new WsPool[2];  // (never destroyed: the HIP runtime may be gone by then)
@@ -276,8 +307,7 @@ static void launch_scan_big(hipStream_t st, int64_t ntiles, const uint32_t* c0, 
   hipLaunchKernelGGL(gf_k_compact_scan_add, dim3((unsigned)nr), dim3(1024), 0, st, o0, ntiles, (const int64_t*)round_offsets);
 }
 
-static int acquire_workspace(gf_index* mix, hipStream_t st, size_t need, void** out, bool pair = false) {
-  Workspace& W = ws_pool(pair).ws[WsKey{mix->device, st}];  // caller holds the pool's mutex
+static int acquire_workspace(Workspace& W, hipStream_t st, size_t need, void** out) {  // caller holds W.mu
   if (W.bytes < need) {
     if (W.base) {
       GF_HIP(hipStreamSynchronize(st));  // earlier calls on this stream may still use it
@@ -674,6 +704,15 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
 
 void gf_index_free(gf_index* idx) {
   if (!idx) return;
+  if (idx->open_streams.load() > 0) {
+    // a gf_stream keeps a pointer to its index (device, table, events): freeing the index under it would be a
+    // use-after-free in gf_stream_collect / gf_stream_close.  The contract (gfmatch.h) is "close the streams first";
+    // a host that breaks it gets a message and a leaked index instead of a crash.
+    fprintf(stderr, "gfmatch: gf_index_free with %d gf_stream(s) still open: index NOT freed (close the streams first)\n",
+            idx->open_streams.load());
+    g_err = "gf_index_free: gf_streams of this index are still open";
+    return;
+  }
   DeviceGuard guard(idx->device);
   delete idx;
 }
@@ -763,10 +802,11 @@ static int map_span_device(const gf_index* idx, const ReadSrc& src, const int64_
     // that covers the merged reads of 2 x 150 — and lists for the wave-per-read kernels of longer reads
     const int lmax = std::min<int>(max_read_len, 320);
     const int pw = lmax <= 160 ? 10 : (lmax <= 256 ? 16 : 20);
-    std::lock_guard<std::mutex> ws_lock(ws_pool(false).mu);  // held until this call's launches are queued
+    const std::shared_ptr<Workspace> wse = ws_pool(false).entry(idx->device, st);
+    std::lock_guard<std::mutex> ws_lock(wse->mu);  // held until this call's launches are queued
     const FlatPlan p = flat_plan(n, idx->n_cus, pw, max_read_len > lmax);
     void* ws_base = nullptr;
-    int wrc = acquire_workspace(mix, st, p.bytes(), &ws_base);
+    int wrc = acquire_workspace(*wse, st, p.bytes(), &ws_base);
     if (wrc != GF_OK) return wrc;
     const FlatWs w = flat_carve((uint8_t*)ws_base, p);
     hipEvent_t* ev = prof ? mix->ev_stage : nullptr;
@@ -968,11 +1008,18 @@ struct LaneLease {
 
 static const int GF_MAX_LANES = 8;
 
-void gf_index::free_lanes() {
+void gf_index::free_lanes() {  // (the destructor has waited for the device)
   for (HostLane* L : lanes) {
     if (L->arena) (void)hipFree(L->arena);
     if (L->pinned) (void)hipHostFree(L->pinned);
-    if (L->st) (void)hipStreamDestroy(L->st);
+    if (L->st) {
+      // every host-buffer call went through gf_map_reads_device(L->st): its mapping workspace (64-112 B per read of
+      // the largest batch) is keyed by this stream in the process-wide pool and would outlive it — a host that
+      // rebuilds the index per CSV left one multi-GB workspace behind per freed index
+      ws_pool(false).drop(device, L->st);
+      ws_pool(true).drop(device, L->st);
+      (void)hipStreamDestroy(L->st);
+    }
     delete L;
   }
   lanes.clear();
@@ -1179,6 +1226,10 @@ int gf_map_reads(const gf_index* idx, const char* bases, const int64_t* offsets,
   // any (ordered compaction on the device): 48 bytes per hit instead of 32 per read
   const int64_t cap = std::max<int64_t>(1024, n / 16);
   HostStage S;
+  // Whatever way this call ends, nothing may still be in flight on the lane when it does: the copies below land in
+  // local pageable buffers, and the lane goes back to the pool (an error between an asynchronous copy
+  // and its synchronisation left both dangling).
+  struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drain{L.st};
   rc = stage_and_map(mix, L, bases, offsets, n, cap, S);
   if (rc != GF_OK) return rc;
   rc = gf_compact_hits_device(idx, S.counts, S.matches, n, 0, S.hits, cap, S.total, S.compact_ws, (void*)L.st);
@@ -1230,6 +1281,7 @@ int gf_map_reads_hits(const gf_index* idx, const char* bases, const int64_t* off
   if (rc != GF_OK) return rc;
   HostLane& L = *lease.lane;
   HostStage S;
+  struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drain{L.st};  // (see gf_map_reads)
   rc = stage_and_map(mix, L, bases, offsets, n, cap, S);
   if (rc != GF_OK || n == 0) return rc;
   rc = gf_compact_hits_device(idx, S.counts, S.matches, n, read_id_base, S.hits, cap, S.total, S.compact_ws, (void*)L.st);
@@ -1704,7 +1756,6 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   if (merged_max > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "2 * max_read_len exceeds GF_MAX_READ_LEN");
   DeviceGuard guard(idx->device);
   hipStream_t st = (hipStream_t)stream;
-  gf_index* mix = const_cast<gf_index*>(idx);
   GF_HIP(hipMemsetAsync(d_totals, 0, 8 * sizeof(int64_t), st));
   if (n == 0) return GF_OK;
   if (retry_cap <= 0) retry_cap = gf_scan_pairs_retry_capacity(n);
@@ -1732,9 +1783,10 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   const size_t o_rb = cv.take((size_t)retry_bytes_cap + 64), o_rq = cv.take((size_t)retry_bytes_cap + 64);
   const size_t o_cR = cv.take((size_t)retry_cap), o_mR = cv.take((size_t)retry_cap * 32);
 
-  std::lock_guard<std::mutex> lk(ws_pool(true).mu);  // held until this call's launches are queued
+  const std::shared_ptr<Workspace> pwse = ws_pool(true).entry(idx->device, st);
+  std::lock_guard<std::mutex> lk(pwse->mu);  // held until this call's launches are queued
   void* base = nullptr;
-  int rc = acquire_workspace(mix, st, cv.off, &base, true);
+  int rc = acquire_workspace(*pwse, st, cv.off, &base);
   if (rc != GF_OK) return rc;
   uint8_t* wp = (uint8_t*)base;
   int32_t* m_len = (int32_t*)(wp + o_mlen); int32_t* m_diff = (int32_t*)(wp + o_mdiff); int64_t* m_off = (int64_t*)(wp + o_moff);
@@ -1826,6 +1878,7 @@ struct gf_stream {
   };
   std::vector<Slot> slots;
   int head = 0, tail = 0, live = 0;
+  bool counted = false;  // registered in ix->open_streams
 };
 
 int gf_copy_from_host_device(const gf_index* idx, const void* h_src, void* d_dst, int64_t nbytes, void* stream) {
@@ -1854,6 +1907,7 @@ void gf_host_free(void* p) {
 void gf_stream_close(gf_stream* s) {
   if (!s) return;
   DeviceGuard guard(s->ix->device);
+  if (s->counted) s->ix->open_streams.fetch_sub(1);
   for (auto& sl : s->slots) {
     if (sl.st) (void)hipStreamSynchronize(sl.st);
     if (sl.arena) (void)hipFree(sl.arena);
@@ -1862,13 +1916,7 @@ void gf_stream_close(gf_stream* s) {
     if (sl.st) {
       (void)hipEventDestroy(sl.done);
       // the mapping workspace cached for this stream goes with it
-      WsPool& P = ws_pool(false);
-      std::lock_guard<std::mutex> lk(P.mu);
-      auto it = P.ws.find(WsKey{s->ix->device, sl.st});
-      if (it != P.ws.end()) {
-        if (it->second.base) (void)hipFree(it->second.base);
-        P.ws.erase(it);
-      }
+      ws_pool(false).drop(s->ix->device, sl.st);
       (void)hipStreamDestroy(sl.st);
     }
   }
@@ -1882,6 +1930,8 @@ int gf_stream_open(const gf_index* idx, int64_t max_reads, int64_t max_bytes, in
   DeviceGuard guard(idx->device);
   std::unique_ptr<gf_stream, void (*)(gf_stream*)> s(new gf_stream(), gf_stream_close);
   s->ix = const_cast<gf_index*>(idx);
+  s->ix->open_streams.fetch_add(1);
+  s->counted = true;
   s->depth = depth;
   s->max_reads = max_reads;
   s->max_bytes = max_bytes;
@@ -1995,6 +2045,98 @@ int64_t gf_index_export(const gf_index* idx, int32_t what, void* out, int64_t ca
   return bytes;
 }
 
+// ---- the exchange: per-rank hit lists -> the global list, one all-gather over RCCL ----
+struct gf_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+};
+
+#define GF_NCCL(expr)                                                                              \
+  do {                                                                                             \
+    ncclResult_t r_ = (expr);                                                                      \
+    if (r_ != ncclSuccess) {                                                                       \
+      char buf_[512];                                                                              \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+      return fail(GF_ERR_COMM, buf_);                                                              \
+    }                                                                                              \
+  } while (0)
+
+static_assert(GF_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "gf_comm id size");
+
+int gf_comm_unique_id(void* out_id) {
+  if (!out_id) return fail(GF_ERR_ARG, "out_id is null");
+  ncclUniqueId id;
+  GF_NCCL(ncclGetUniqueId(&id));
+  memcpy(out_id, &id, sizeof id);
+  return GF_OK;
+}
+
+int gf_comm_init(const void* id, int32_t rank, int32_t world, int32_t device, gf_comm** out) {
+  if (!out) return fail(GF_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (!id || world < 1 || world > GF_EXCH_MAX_WORLD || rank < 0 || rank >= world)
+    return fail(GF_ERR_ARG, "bad id, rank or world (1..64 ranks)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(GF_ERR_NO_DEVICE, "no HIP device available (gfmatch has no CPU fallback)");
+  if (device < 0) GF_HIP(hipGetDevice(&device));
+  if (device >= ndev) return fail(GF_ERR_NO_DEVICE, "device ordinal out of range");
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(GF_ERR_NO_DEVICE, "hipSetDevice failed");
+  std::unique_ptr<gf_comm> c(new gf_comm());
+  c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  GF_NCCL(ncclCommInitRank(&c->comm, world, uid, rank));
+  *out = c.release();
+  return GF_OK;
+}
+
+int gf_comm_rank(const gf_comm* comm, int32_t* rank, int32_t* world) {
+  if (!comm) return fail(GF_ERR_ARG, "null communicator");
+  if (rank) *rank = comm->rank;
+  if (world) *world = comm->world;
+  return GF_OK;
+}
+
+void gf_comm_free(gf_comm* comm) {
+  if (!comm) return;
+  DeviceGuard guard(comm->device);
+  if (comm->comm) (void)ncclCommDestroy(comm->comm);
+  delete comm;
+}
+
+// send block | receive blocks, (cap + 1) records each
+int64_t gf_allgather_workspace_bytes(int32_t world, int64_t cap) {
+  if (world < 1 || cap < 0) return 0;
+  return ((int64_t)world + 1) * (cap + 1) * (int64_t)sizeof(gf_hit) + 256;
+}
+
+static int exch_grid(int64_t records) { return (int)std::max<int64_t>(1, std::min<int64_t>((3 * records + 255) / 256, 1024)); }
+
+int gf_pack_gathered_hits_device(const void* d_recv, int32_t world, int64_t cap, void* d_merged, void* d_totals, void* stream) {
+  if (world < 1 || world > GF_EXCH_MAX_WORLD || cap < 0) return fail(GF_ERR_ARG, "bad world (1..64) or cap");
+  if (!d_recv || !d_totals || (cap > 0 && !d_merged)) return fail(GF_ERR_ARG, "null device pointer");
+  hipLaunchKernelGGL(gf_k_exch_pack, dim3(exch_grid((int64_t)world * cap)), dim3(256), 0, (hipStream_t)stream,
+                     (const gf_hit*)d_recv, world, cap, (gf_hit*)d_merged, (int64_t*)d_totals);
+  GF_HIP(hipGetLastError());
+  return GF_OK;
+}
+
+int gf_allgather_hits_device(gf_comm* comm, const void* d_hits, const void* d_n_hits, int64_t cap, void* d_merged,
+                             void* d_totals, void* d_workspace, void* stream) {
+  if (!comm || cap < 0) return fail(GF_ERR_ARG, "null communicator or negative cap");
+  if (!d_n_hits || !d_totals || !d_workspace || (cap > 0 && (!d_hits || !d_merged))) return fail(GF_ERR_ARG, "null device pointer");
+  DeviceGuard guard(comm->device);
+  hipStream_t st = (hipStream_t)stream;
+  gf_hit* send = (gf_hit*)(((uintptr_t)d_workspace + 255) & ~(uintptr_t)255);
+  gf_hit* recv = send + (cap + 1);
+  hipLaunchKernelGGL(gf_k_exch_stage, dim3(exch_grid(cap)), dim3(256), 0, st, (const gf_hit*)d_hits, (const int64_t*)d_n_hits, cap, send);
+  GF_HIP(hipGetLastError());
+  GF_NCCL(ncclAllGather(send, recv, (size_t)(cap + 1) * sizeof(gf_hit), ncclChar, comm->comm, st));
+  return gf_pack_gathered_hits_device(recv, comm->world, cap, d_merged, d_totals, stream);
+}
+
 int gf_index_trim(gf_index* idx) {
   if (!idx) return fail(GF_ERR_ARG, "null index");
   DeviceGuard guard(idx->device);
@@ -2009,15 +2151,22 @@ int gf_index_trim(gf_index* idx) {
   // Calls queued on the workspaces' streams may still use them: wait for the whole device, not stream by
   // stream — a stream the caller has destroyed since is still a key here, and must not be touched.
   GF_HIP(hipDeviceSynchronize());
-  for (int k = 1; k >= 0; --k) {  // (lock order: pair pool, then map pool — as gf_scan_pairs_device takes them)
+  for (int k = 1; k >= 0; --k) {
     WsPool& P = ws_pool(k == 1);
-    std::lock_guard<std::mutex> lk(P.mu);
-    for (auto& kv : P.ws)
-      if (kv.first.device == idx->device && kv.second.base) {
-        GF_HIP(hipFree(kv.second.base));
-        kv.second.base = nullptr;
-        kv.second.bytes = 0;
+    std::vector<std::shared_ptr<Workspace>> mine;
+    {
+      std::lock_guard<std::mutex> lk(P.mu);
+      for (auto& kv : P.ws)
+        if (kv.first.device == idx->device && kv.second) mine.push_back(kv.second);
+    }
+    for (auto& e : mine) {
+      std::lock_guard<std::mutex> lk(e->mu);
+      if (e->base) {
+        GF_HIP(hipFree(e->base));
+        e->base = nullptr;
+        e->bytes = 0;
       }
+    }
   }
   block_trim(idx->device);  // device blocks of freed indexes
   return GF_OK;

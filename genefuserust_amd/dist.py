@@ -111,3 +111,91 @@ class HitExchange:
         merged = torch.empty((trash + 1, HIT_WORDS), dtype=torch.int64, device=recv.device)
         merged.index_copy_(0, idx.reshape(-1), recv[:, 1:, :].reshape(-1, HIT_WORDS))
         return merged, total, overflow
+
+
+class RcclHitExchange:
+    """The merge through the C ABI: ``gf_comm_*`` + ``gf_allgather_hits_device`` (include/gfmatch.h) — RCCL called
+    by libgfmatch.so itself, which is what a Rust / C++ host binds.  ``torch.distributed`` only
+    carries the 128-byte communicator id (one broadcast) — any launcher's side channel would do.
+
+    ``start`` queues stage -> ncclAllGather -> pack on a side stream behind the work already queued on the
+    caller's stream and returns; ``finish`` makes the caller's stream wait for that batch and hands out
+    (merged int64[world*cap, 6], totals int64[2 + world]) — totals[0] records of ``merged`` are the global ordered
+    list, totals[1] != 0 says a rank had more than ``cap`` records.  Two buffer sets: batch k+1 may be started
+    while batch k is still in flight.
+    """
+
+    def __init__(self, cap: int, device, group=None, depth: int = 2):
+        from . import _lib
+        import ctypes as C
+        self._lib, self._C = _lib, C
+        L = _lib.lib()
+        self.cap, self.group = int(cap), group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = torch.device(device)
+        idt = torch.zeros(_lib.GF_COMM_ID_BYTES, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_uint8 * _lib.GF_COMM_ID_BYTES)()
+            _lib.check(L.gf_comm_unique_id(buf))
+            idt = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        if dist.get_backend(group) == "nccl":   # (the backend moves device tensors only)
+            idd = idt.to(self.device)
+            dist.broadcast(idd, src=src, group=group)
+            idt = idd.cpu()
+        else:
+            dist.broadcast(idt, src=src, group=group)
+        idb = (C.c_uint8 * _lib.GF_COMM_ID_BYTES).from_buffer_copy(idt.numpy().tobytes())
+        h = C.c_void_p()
+        _lib.check(L.gf_comm_init(idb, self.rank, self.world, self.device.index or 0, C.byref(h)))
+        self._h = h
+        ws = int(L.gf_allgather_workspace_bytes(self.world, self.cap))
+        self.side = torch.cuda.Stream(device=self.device)
+        self.sets = [dict(ws=torch.empty(ws, dtype=torch.uint8, device=self.device),
+                          merged=torch.empty((max(self.world * self.cap, 1), HIT_WORDS), dtype=torch.int64, device=self.device),
+                          totals=torch.zeros(2 + self.world, dtype=torch.int64, device=self.device),
+                          done=torch.cuda.Event()) for _ in range(depth)]
+        self.slot = 0
+
+    def start(self, hits: torch.Tensor, n_hits: torch.Tensor):
+        k = self.slot
+        self.slot = (self.slot + 1) % len(self.sets)
+        s = self.sets[k]
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self.side.wait_event(ready)       # the list is complete when the caller's queued work is
+        self._lib.check(self._lib.lib().gf_allgather_hits_device(
+            self._h, hits.data_ptr(), n_hits.data_ptr(), self.cap,   # (only the first min(count, cap) records are read)
+            s["merged"].data_ptr(), s["totals"].data_ptr(), s["ws"].data_ptr(), self.side.cuda_stream))
+        s["done"].record(self.side)
+        s["keep"] = (hits, n_hits)        # (alive until the side stream has read them)
+        return k
+
+    def finish(self, handle):
+        s = self.sets[handle]
+        torch.cuda.current_stream(self.device).wait_event(s["done"])
+        return s["merged"], s["totals"]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self._lib.lib().gf_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pack_gathered_hits(recv: torch.Tensor, world: int, cap: int):
+    """gf_pack_gathered_hits_device on a receive buffer int64[world * (cap + 1), 6] (record 0 of every block = its
+    count in word 0): (merged int64[world*cap, 6], totals int64[2 + world])."""
+    from . import _lib
+    merged = torch.empty((max(world * cap, 1), HIT_WORDS), dtype=torch.int64, device=recv.device)
+    totals = torch.zeros(2 + world, dtype=torch.int64, device=recv.device)
+    _lib.check(_lib.lib().gf_pack_gathered_hits_device(recv.data_ptr(), world, cap, merged.data_ptr(), totals.data_ptr(),
+                                                      torch.cuda.current_stream(recv.device).cuda_stream))
+    return merged, totals

@@ -80,7 +80,9 @@ def scan_pair_text_stream(indexer: Indexer, r1_text: np.ndarray, r2_text: np.nda
     def start_upload(slot: int):
         """The copy of the slot's next chunk, on a host thread of its own: the calls that queue it block that
         thread, not the one that launches the kernels of the chunk being processed."""
-        nbytes = [chunk_bytes - s.carry_len for s in sides]   # (the carries are final here: read on this thread)
+        # (the carry lengths read here are those of the chunk processed LAST, not of the one in flight: the balancing
+        #  of the two files lags one chunk behind — harmless, a slot always has room for chunk_bytes behind CARRY_MAX)
+        nbytes = [max(chunk_bytes - s.carry_len, 1) for s in sides]
         wait_for = free[slot]
 
         def run():

@@ -279,3 +279,32 @@ def make_pairs(genes: GeneSet, n: int, read_len: int = 150, mix: str = "PANEL", 
     offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
     return PairBatch(out["lb"].reshape(-1), out["lq"].reshape(-1), out["rb"].reshape(-1), out["rq"].reshape(-1), offsets,
                      kinds, flens)
+
+
+def make_pair_reads(genes: GeneSet, n_pairs: int, read_len: int = 150, mix: str = "PANEL", seed: int = 20240116,
+                    device: str = "cpu", block: int = 1 << 21, n_frac: float = 0.002) -> ReadBatch:
+    """The reads of `make_pairs` as ONE batch in FASTQ order — read 2i = R1 of pair i, read 2i+1 = its R2
+    (the reverse complement of the fragment's far end) — which is how a pair-end scan presents them to
+    Indexer::map_read (pescanner.rs:473-515).  SURVEY.md §8(d): fragments N(300, 30); 0.2 % of the reads from
+    a gene hold one N.  Made block by block (own seed each) so that 100 M pairs never hold their qualities."""
+    dev = torch.device(device)
+    L = read_len
+    out = torch.empty((n_pairs, 2, L), dtype=torch.uint8, device=dev)
+    kinds = torch.empty((n_pairs, 2), dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    for k, p0 in enumerate(range(0, n_pairs, block)):
+        m = min(block, n_pairs - p0)
+        pb = make_pairs(genes, m, read_len=L, mix=mix, seed=seed + 7919 * k, device=device)
+        out[p0:p0 + m, 0] = pb.l_bases.view(m, L)
+        out[p0:p0 + m, 1] = pb.r_bases.view(m, L)
+        kinds[p0:p0 + m] = pb.kinds[:, None]
+        del pb
+        if n_frac > 0:
+            gen.manual_seed(seed + 7919 * k + 1)
+            blk = out[p0:p0 + m].view(2 * m, L)
+            has_n = (torch.rand(2 * m, generator=gen, device=dev) < n_frac) & (kinds[p0:p0 + m].reshape(-1) > 0)
+            rows = has_n.nonzero().flatten()
+            cols = torch.randint(0, L, (rows.numel(),), generator=gen, device=dev)
+            blk[rows, cols] = ord("N")
+    offsets = torch.arange(2 * n_pairs + 1, device=dev, dtype=torch.int64) * L
+    return ReadBatch(out.reshape(-1), offsets, kinds.reshape(-1))

@@ -373,6 +373,9 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
  * is asynchronous and the buffers must stay untouched until that pack is collected; from pageable
  * memory the runtime stages the copy before gf_stream_submit returns.
  * A gf_stream belongs to one thread at a time; several streams may share an index.
+ * LIFETIME: a gf_stream keeps a pointer to its index — close every stream before gf_index_free.  The library counts
+ * the open streams of an index: gf_index_free on an index that still has one prints a message and does NOT free it
+ * (a leak, where the alternative is a use-after-free in gf_stream_collect / gf_stream_close).
  * Errors: GF_ERR_CAPACITY when a pack exceeds max_reads / max_bytes or every slot is in flight. */
 typedef struct gf_stream gf_stream;
 int gf_stream_open(const gf_index* idx, int64_t max_reads, int64_t max_bytes, int32_t depth, gf_stream** out);
@@ -385,6 +388,41 @@ void gf_host_free(void* p);
 /* hipMemcpyAsync host -> device on `stream`, for hosts that hold no HIP binding of their own (a
  * streamed FASTQ: genefuserust_amd/scan_stream.py).  Asynchronous when h_src is pinned. */
 int gf_copy_from_host_device(const gf_index* idx, const void* h_src, void* d_dst, int64_t nbytes, void* stream);
+
+/* --- multi-GPU: the one exchange of the path ----------------------------------------
+ * One process per GPU; reads shard into contiguous ranges (rank r maps reads [r n / R, (r+1) n / R) with
+ * read_id_base = its first read), every rank builds the same index, nothing is exchanged while mapping.
+ * The per-rank gf_hit lists (gf_compact_hits_device: ascending read id) are merged by ONE all-gather over
+ * RCCL (xGMI inside a node); concatenated in rank order they are the list one GPU would produce, on
+ * every rank.  The reference has no counterpart (one process: consumer threads push under a mutex,
+ * fusion_mapper.rs:253-275); its split of the work over workers is fusion_scan.rs:103-116,143-181.
+ *
+ * gf_comm_unique_id: rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by
+ *   whatever the host has (a file, a socket, MPI, torch.distributed); gf_comm_init is collective over the
+ *   `world` ranks that were given that id (ncclCommInitRank on `device`).  Groups are just communicators
+ *   made from another id (multi-CSV mode: the ranks that share a CSV).
+ * gf_allgather_hits_device: every rank passes its list (d_hits, *d_n_hits records, device memory, 16-byte
+ *   aligned) and the same cap.  Queued on `stream`: stage -> ncclAllGather of (cap + 1) records per rank
+ *   -> pack.  d_merged (world * cap records) receives the merged list; d_totals (int64[2 + world]):
+ *   [0] records in it, [1] 1 when a rank had more than cap records (that rank's list is cut at cap: run
+ *   the batch again with a larger cap), [2 + r] rank r's own count.  d_workspace:
+ *   gf_allgather_workspace_bytes(world, cap) bytes.  Nothing is synchronised: the exchange of one batch
+ *   can run on a side stream while the next batch is being mapped.
+ * gf_pack_gathered_hits_device: the pack step alone, on a receive buffer of `world` blocks of (cap + 1)
+ *   records whose record 0 holds the block's count in read_id (what the all-gather delivers) — for hosts
+ *   that bring their own transport, and for the tests. */
+#define GF_COMM_ID_BYTES 128
+#define GF_ERR_COMM (-6)          /* an RCCL call failed */
+typedef struct gf_comm gf_comm;
+int gf_comm_unique_id(void* out_id);
+int gf_comm_init(const void* id, int32_t rank, int32_t world, int32_t device, gf_comm** out);
+int gf_comm_rank(const gf_comm* comm, int32_t* rank, int32_t* world);
+void gf_comm_free(gf_comm* comm);
+int64_t gf_allgather_workspace_bytes(int32_t world, int64_t cap);
+int gf_allgather_hits_device(gf_comm* comm, const void* d_hits, const void* d_n_hits, int64_t cap, void* d_merged,
+                             void* d_totals, void* d_workspace, void* stream);
+int gf_pack_gathered_hits_device(const void* d_recv, int32_t world, int64_t cap, void* d_merged, void* d_totals,
+                                 void* stream);
 
 /* --- instrumentation -------------------------------------------------------
  * With profiling on, gf_map_reads_device brackets its mapping kernel with HIP

@@ -69,3 +69,51 @@ def test_stream_equals_one_shot(gpu_device, pinned):
     got = np.concatenate(got)
     assert got.tobytes() == want.tobytes()
     ix.close()
+
+
+def test_host_api_indexes_leave_no_workspace_behind(gpu_device):
+    """every host-buffer call maps on a lane's stream and gives that stream a workspace in the
+    process-wide pool; freeing the index must take it along.  Build, map through the host API and free many
+    indexes (multi-CSV mode with host buffers): the device's free memory must not creep."""
+    import torch
+    from genefuserust_amd import Indexer, synth
+    genes = synth.make_geneset("IDX-T", scale=0.05)
+    rb = synth.make_reads(genes, 300_000, read_len=150, mix="PANEL", seed=5)
+    bases, offsets = rb.bases.numpy(), rb.offsets.numpy()
+
+    def one():
+        ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+        ix.make_index()
+        h = ix.map_reads_hits(bases, offsets)
+        ix.close()
+        return h.shape[0]
+
+    first = one()
+    one()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(gpu_device)[0]
+    for _ in range(12):
+        assert one() == first
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(gpu_device)[0]
+    # a leaked workspace is 64 B x 300 K reads = 19 MB per index: 12 of them would be 230 MB
+    assert free0 - free1 < 32 << 20, (free0, free1)
+
+
+def test_index_free_with_an_open_stream_is_refused(gpu_device, capfd):
+    """gf_stream keeps a pointer to its index: gf_index_free under an open stream leaks the index (with a message)
+    instead of leaving the stream dangling; after gf_stream_close the index is freed normally."""
+    from genefuserust_amd import Indexer, synth, _lib
+    from genefuserust_amd.stream import MapStream
+    genes = synth.make_geneset("IDX-T", scale=0.02)
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    rb = synth.make_reads(genes, 2000, read_len=150, mix="PANEL", seed=6)
+    ms = MapStream(ix, max_reads=4000, max_bytes=4000 * 150, depth=2)
+    h = ix._handle()
+    _lib.lib().gf_index_free(h)          # refused: the stream is open
+    assert b"still open" in _lib.lib().gf_last_error()
+    ms.submit(rb.bases.numpy(), rb.offsets.numpy())
+    assert ms.collect().shape[0] >= 0    # the index is still there
+    ms.close()
+    ix.close()

@@ -124,3 +124,67 @@ def test_hit_exchange_on_the_device(gpu_device):
         assert bool(overflow)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_pack_kernel_on_synthetic_receive_buffers(gpu_device, world):
+    """gf_pack_gathered_hits_device (the device half of gf_allgather_hits_device) on receive buffers as the
+    all-gather delivers them for 1, 2, 3 and 8 ranks: ragged counts, an empty rank, a rank over capacity."""
+    from genefuserust_amd.dist import pack_gathered_hits
+    dev = torch.device("cuda", gpu_device)
+    rng = np.random.default_rng(world)
+    cap = 700
+    counts = [int(c) for c in rng.integers(0, cap + 1, size=world)]
+    if world >= 2:
+        counts[1] = 0
+    if world >= 3:
+        counts[2] = cap
+    recv = torch.full((world * (cap + 1), HIT_WORDS), -7, dtype=torch.int64)
+    want, base = [], 0
+    for r, c in enumerate(counts):
+        blk = recv[r * (cap + 1):(r + 1) * (cap + 1)]
+        blk[0] = 0
+        blk[0, 0] = c
+        rows = torch.arange(base, base + c, dtype=torch.int64)[:, None] * 10 + torch.arange(HIT_WORDS)[None, :]
+        blk[1:1 + c] = rows
+        want.append(rows)
+        base += c
+    merged, totals = pack_gathered_hits(recv.to(dev), world, cap)
+    tot = totals.cpu().tolist()
+    assert tot[0] == sum(counts) and tot[1] == 0 and tot[2:] == counts
+    assert torch.equal(merged[: tot[0]].cpu(), torch.cat(want))
+    # a rank over capacity: its block is cut at cap and the flag says so
+    recv[0, 0] = cap + 5
+    merged, totals = pack_gathered_hits(recv.to(dev), world, cap)
+    tot = totals.cpu().tolist()
+    assert tot[1] == 1 and tot[2] == cap + 5 and tot[0] == cap + sum(counts[1:])
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_through_the_c_abi_one_rank(gpu_device):
+    """gf_comm_unique_id / gf_comm_init / gf_allgather_hits_device / gf_comm_free with RCCL itself, one rank (a test
+    box has one GPU): stage, ncclAllGather and pack on a side stream, two batches in flight, the overflow flag."""
+    from genefuserust_amd.dist import RcclHitExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda", gpu_device)
+    dist.init_process_group("gloo", rank=0, world_size=1)   # carries the id only
+    try:
+        hits, n_hits = _fake_hits(0, 5000, cap=6000)
+        ex = RcclHitExchange(cap=2048, device=dev)
+        h1 = ex.start(hits.to(dev), n_hits.to(dev))
+        h2 = ex.start(hits[:10].to(dev), torch.tensor([7], device=dev))
+        merged, totals = ex.finish(h1)
+        t = totals.cpu().tolist()
+        assert t[0] == int(n_hits) and t[1] == 0 and t[2] == int(n_hits)
+        assert torch.equal(merged[: t[0]].cpu(), hits[: int(n_hits)])
+        merged, totals = ex.finish(h2)
+        assert int(totals[0]) == 7 and torch.equal(merged[:7].cpu(), hits[:7])
+        small = RcclHitExchange(cap=100, device=dev)
+        _, totals = small.finish(small.start(hits.to(dev), n_hits.to(dev)))
+        assert int(totals[1]) == 1 and int(totals[0]) == 100
+        small.close()
+        ex.close()
+    finally:
+        dist.destroy_process_group()
