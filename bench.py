@@ -567,6 +567,43 @@ def h2d_inclusive(ix, reads, n, L):
         out = {"reads_per_s": ns / dt, "host_GBps": (ns * L + 8 * (ns + 1)) / dt / 1e9, "reads": ns, "pack_reads": pack,
                "hits": int(total), "bytes_per_read": L + 8,
                "entry": "gf_stream_submit/collect, pinned host buffers, depth 3"}
+    # the same packs handed over in packed form (gf_pack_bases_host + gf_stream_submit_packed): 6 bytes per 16 bases over
+    # the link.  Two figures: the stream alone from pre-packed pinned memory (what a host that keeps its reads packed
+    # gets — multi-CSV mode, a FASTQ parser that emits the form), and the host packer's own rate on this box's cores.
+    try:
+        from genefuserust_amd.stream import pack_bases_host
+        cores = usable_cores()
+        t0 = time.perf_counter()
+        pk, iv = pack_bases_host(hb, threads=cores, pinned=True)
+        t_first = time.perf_counter() - t0          # (includes the first touch of the pinned output)
+        from genefuserust_amd import _lib as _gl
+        t0 = time.perf_counter()
+        _gl.check(_gl.lib().gf_pack_bases_host(hb.ctypes.data, hb.size, pk.ctypes.data, iv.ctypes.data, cores))
+        t_pack = time.perf_counter() - t0
+        with MapStream(ix, max_reads=pack, max_bytes=pack * L + 64, depth=3) as ms:
+            for rep in range(2):
+                t0 = time.perf_counter()
+                total_p = 0
+                inflight = 0
+                for p0 in range(0, ns, pack):
+                    p1 = min(ns, p0 + pack)
+                    if inflight == ms.depth:
+                        total_p += ms.collect().shape[0]
+                        inflight -= 1
+                    ms.submit_packed(pk, iv, ho[p0:p1 + 1], read_id_base=p0)
+                    inflight += 1
+                while inflight:
+                    total_p += ms.collect().shape[0]
+                    inflight -= 1
+                dtp = time.perf_counter() - t0
+        out["packed"] = {"reads_per_s_prepacked": ns / dtp, "host_GBps_prepacked": (ns * L * 0.375 + 8 * (ns + 1)) / dtp / 1e9,
+                         "bytes_per_read": L * 0.375 + 8, "hits": int(total_p), "same_hits_as_ascii": int(total_p) == int(total),
+                         "host_pack_GBps_of_ascii": hb.size / t_pack / 1e9, "host_pack_threads": cores,
+                         "host_pack_reads_per_s": ns / t_pack, "host_pack_first_call_s": round(t_first, 3),
+                         "entry": "gf_pack_bases_host (AVX2) + gf_stream_submit_packed, pinned, depth 3"}
+        del pk, iv
+    except Exception as e:  # noqa: BLE001 — a reported extra
+        out["packed"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # the link alone: one large pinned H2D copy
     d = torch.empty(ns * L, dtype=torch.uint8, device=reads.bases.device)
     t = torch.from_numpy(hb)

@@ -125,6 +125,10 @@ def lib() -> C.CDLL:
     L.gf_packed_chunks.restype = i64
     L.gf_pack_bases_device.argtypes = [vp, vp, i64, vp, vp, vp]
     L.gf_pack_bases_device.restype = C.c_int
+    L.gf_pack_bases_host.argtypes = [vp, i64, vp, vp, i32]
+    L.gf_pack_bases_host.restype = C.c_int
+    L.gf_stream_submit_packed.argtypes = [vp, vp, vp, vp, i64, i64]
+    L.gf_stream_submit_packed.restype = C.c_int
     L.gf_map_reads_packed_device.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp]
     L.gf_map_reads_packed_device.restype = C.c_int
     L.gf_compact_workspace_bytes.argtypes = [i64]

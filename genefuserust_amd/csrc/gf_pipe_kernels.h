@@ -744,22 +744,34 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
 // v1 + h + left < 20 or v2 + h + left < 10 -> [].  Survivors go to the exact kernel.
 // (One kernel doing both kept every wave in the bucket loop for as long as its unluckiest
 // lane: most of its instructions were executed for a handful of lanes.)
+#define GF_ENTRY_ROUND1 0x40000000u  // in w[1]: a read without a candidate diagonal that outlived round 0 of the look-ups below
+
 template <int PW>
 __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW<PW>* __restrict__ list_b,
                                                          const unsigned int* __restrict__ blk_cnt, int64_t per_block,
                                                          uint8_t* __restrict__ counts,
-                                                         unsigned int* __restrict__ blk_cnt2, int phase, int nparts) {
+                                                         unsigned int* __restrict__ blk_cnt2, int phase, int nparts,
+                                                         int sweep) {
   // nparts 1: the whole filter in one pass.  A filter larger than an XCD's L2 is asked in nparts
   // passes instead, each touching one part of its words (which then stays in the L2): phase p
-  // asks the look-ups that fall in part p and leaves the others standing.  A background read
-  // has to ask nearly all of its windows before the gate can stop it, so the split costs it
-  // nothing but the extra trips of its list entry.
+  // asks the look-ups that fall in part p and leaves the others standing.
+  //
+  // Reads WITH a candidate diagonal (v1 > 0) ask every window the verification left open, part by part, and die
+  // by  v1 + P < 20 or v2 + P < 10;  after the last part they are marked GF_ENTRY_FILTERED.
+  // Reads WITHOUT one (background, mostly; they come here when the filter is too large for seed+verify to ask it
+  // itself) go by the bound of gf_table.h, like seed+verify's inline pass (r03): sweep 0 asks the EVEN pairs of
+  // windows, part by part; after its last part the bound decides — at most 12 votes for a 150-base read whose
+  // even pairs are all ruled out, +3 per false positive, 20 needed.  A survivor is marked GF_ENTRY_ROUND1 and asks
+  // its ODD pairs: those of the last part at once, the others in sweep 1 (launches for parts 0 .. nparts-2 over
+  // what is left — a tenth of the background reads), whose last launch meets the bound again with every pair
+  // asked and marks what still stands GF_ENTRY_FILTERED.  Half the look-ups of the form that asked every pair.
   __shared__ unsigned int s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
   const unsigned int nb = blk_cnt[blockIdx.x];
   const uint32_t part_words = (T.bloom_words + (uint32_t)nparts - 1) / (uint32_t)nparts;
   const uint32_t part_lo = (uint32_t)phase * part_words, part_hi = part_lo + part_words;
+  const bool last_part = sweep == 0 ? phase == nparts - 1 : phase == nparts - 2;  // this launch completes its sweep
   GfPipeEntryW<PW>* my_list = list_b + (int64_t)blockIdx.x * per_block;
   for (unsigned int t0 = 0; t0 < nb; t0 += 256) {
     const unsigned int t = t0 + threadIdx.x;
@@ -771,17 +783,71 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
     for (int k = 0; k < NT; ++k) m[k] = pp[k] = 0;
     if (t < nb) {
       gf_entry_load<PW>(my_list + t, r, v1v2, m, pk);
-      const bool filtered = (v1v2 & GF_ENTRY_FILTERED) != 0;  // seed+verify has asked the filter already
-      v1v2 &= ~GF_ENTRY_FILTERED;
+      const bool filtered = (v1v2 & GF_ENTRY_FILTERED) != 0;  // every window listed has been through the filter
       const int v1 = (int)(v1v2 & 0xFFu), v2 = (int)((v1v2 >> 8) & 0xFFu);
-      int npos = 0, rem = 0;  // not ruled out / not asked yet
-#pragma unroll
-      for (int k = 0; k < NT; ++k) rem += __popc(m[k]);
+      const bool no_candidate = PW == 10 && !filtered && v1 == 0 && v2 == 0 && T.bloom_words != 0;
       bool dead = false;
       if (filtered) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) pp[k] = m[k];
-      } else if (T.bloom_words) {
+      } else if (no_candidate) {
+        // pairs of parity `par` whose filter word lies in this launch's part
+        auto ask = [&](uint32_t par) {
+#pragma unroll
+          for (int j = 0; j < PW; ++j) {
+            const uint32_t byte = (m[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            uint32_t word[2], bits[2];
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+              const uint32_t s14 = __builtin_amdgcn_alignbit(pk[j + 1], pk[j], 16u * (uint32_t)u2 + 8u * par + 4u) & 0x0FFFFFFFu;
+              const uint32_t h2 = GF_BLOOM_HASH((s14));
+              bits[u2] = GF_BLOOM_BITS(h2);
+              const uint32_t widx = GF_BLOOM_WORD(h2, T.bloom_words);
+              const bool mine = widx >= part_lo && widx < part_hi && (byte & (3u << (4 * u2 + 2 * par))) != 0;
+              word[u2] = 0xFFFFFFFFu;  // (not this part's, or nobody to ask for: stands)
+              if (mine) word[u2] = T.bloom[widx];
+            }
+            uint32_t fail2 = 0;
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) fail2 |= ((bits[u2] & ~word[u2]) != 0 ? 1u : 0u) << (4 * u2);
+            fail2 <<= 2 * par;
+            m[j >> 2] &= ~((fail2 | (fail2 << 1)) << (8 * (j & 3)));
+          }
+        };
+        auto bound = [&]() {
+          uint32_t x[NT];
+#pragma unroll
+          for (int k = 0; k < NT; ++k) x[k] = (m[k] | (m[k] >> 1)) & 0x55555555u;
+          return gf_vote_bound_pairs<4 * PW - 3>(x);
+        };
+        const bool round1 = (v1v2 & GF_ENTRY_ROUND1) != 0;
+        if (sweep == 0) {   // (a sweep-0 launch never meets a ROUND1 entry: they are made by its last launch)
+          ask(0u);
+          if (last_part) {
+            dead = bound() < GF_MAJOR_KEYS / 2;
+            if (!dead) {
+              ask(1u);      // the odd pairs of this part at once
+              if (nparts == 1) {
+                dead = bound() < GF_MAJOR_KEYS / 2;
+                v1v2 |= GF_ENTRY_FILTERED;
+              } else {
+                v1v2 |= GF_ENTRY_ROUND1;
+              }
+            }
+          }
+        } else if (round1) {
+          ask(1u);
+          if (last_part) {
+            dead = bound() < GF_MAJOR_KEYS / 2;
+            v1v2 = (v1v2 & ~GF_ENTRY_ROUND1) | GF_ENTRY_FILTERED;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NT; ++k) pp[k] = m[k];
+      } else if (T.bloom_words && sweep == 0) {
+        int npos = 0, rem = 0;  // not ruled out / not asked yet
+#pragma unroll
+        for (int k = 0; k < NT; ++k) rem += __popc(m[k]);
         // windows 2q and 2q+1 share the 14-mer at bases 4q+2 .. 4q+15: one lookup for both.
         // Fully unrolled over the pairs (compile-time shifts on the words in registers),
         // four look-ups in flight per step.
@@ -820,11 +886,14 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
             dead = (v1 + npos + rem < GF_MAJOR_KEYS / 2) || (v2 + npos + rem < GF_MINOR_KEYS / 2);
           }
         }
+        if (last_part) v1v2 |= GF_ENTRY_FILTERED;  // every part has been asked: what stands has passed the filter
       } else {
 #pragma unroll
         for (int k = 0; k < NT; ++k) pp[k] = m[k];
-        const int left = rem;
-        dead = (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
+        int left = 0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) left += __popc(m[k]);
+        dead = !filtered && sweep == 0 && ((v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2));
       }
       if (dead) counts[r] = 0;
       alive = !dead;

@@ -27,6 +27,7 @@
 #include "gf_map_kernels.h"
 #include "gf_merge_kernels.h"
 #include "gf_fastq_kernels.h"
+#include "gf_host_pack.h"
 #include "gf_pipe_kernels.h"
 #include "gf_pair_kernels.h"
 #include "gf_table.h"
@@ -403,12 +404,15 @@ static int launch_flat(const gf_index* idx, const GfTable& T, hipStream_t st, co
   int nparts = T.bloom_in_l2 == 1 ? 2 : 1;
   if (parts_env >= 1 && parts_env <= 8 && T.bloom_in_l2 == 1) nparts = parts_env;
   unsigned int *cnt_in = w.blk_cnt, *cnt_out = w.blk_cnt2;
-  for (int ph = 0; ph < nparts; ++ph) {
-    hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(p.nblk), dim3(256), 0, st, T,
-                       (GfPipeEntryW<PW>*)w.list_b, (const unsigned int*)cnt_in, p.per_block, counts, cnt_out, ph,
-                       nparts);
-    std::swap(cnt_in, cnt_out);
-  }
+  // sweep 0: every part once; sweep 1 (reads of up to 160 bases, more than one part): the odd window pairs of the
+  // reads without a candidate that outlived sweep 0, for the parts before the last (gf_k_probe_filter)
+  for (int sweep = 0; sweep < (nparts > 1 && PW == 10 ? 2 : 1); ++sweep)
+    for (int ph = 0; ph < (sweep == 0 ? nparts : nparts - 1); ++ph) {
+      hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(p.nblk), dim3(256), 0, st, T,
+                         (GfPipeEntryW<PW>*)w.list_b, (const unsigned int*)cnt_in, p.per_block, counts, cnt_out, ph,
+                         nparts, sweep);
+      std::swap(cnt_in, cnt_out);
+    }
   const unsigned int* survivors = cnt_in;  // (the last launch's output)
   if (ev) GF_HIP(hipEventRecord(ev[2], st));
   hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(p.nblk), dim3(256), 0, st, T,
@@ -607,7 +611,11 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
       bloom_in_l2 = 2;
     } else if (kib > 0 && want_mid <= mid_words) {
       words = want_mid;
-      bloom_in_l2 = 1;
+      // (r03, measured on IDX-C with the vote bound's half look-ups: asking this filter from seed+verify itself,
+      //  GF_BLOOM_INLINE_MID=1, 3.87 ms per 20 M reads at 1.5 bits per key, 4.13 at 2.2; the sweeps over the list
+      //  3.93 at 2.2 — no winner: about half of an 8 MiB filter's look-ups miss a 4 MiB L2 either way)
+      static const bool inline_mid = getenv("GF_BLOOM_INLINE_MID") && atoi(getenv("GF_BLOOM_INLINE_MID")) == 1;
+      bloom_in_l2 = inline_mid ? 2 : 1;
     } else if (kib > 0 && big_bpk > 0) {
       words = std::min<uint64_t>(keys * big_bpk / 32 + 1024, (64ull << 20) / 4);
     } else {
@@ -931,6 +939,25 @@ int gf_pack_bases_device(const gf_index* idx, const void* d_bases, int64_t n_bas
   hipLaunchKernelGGL(gf_k_pack_bases, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_bases, n_bases,
                      (uint32_t*)d_pk, (uint16_t*)d_iv, chunks);
   GF_HIP(hipGetLastError());
+  return GF_OK;
+}
+
+int gf_pack_bases_host(const char* bases, int64_t n_bases, uint32_t* pk, uint16_t* iv, int32_t n_threads) {
+  if (n_bases < 0 || !pk || !iv || (n_bases > 0 && !bases)) return fail(GF_ERR_ARG, "bad argument");
+  const int64_t chunks = gf_packed_chunks(n_bases);
+  const unsigned char* b = (const unsigned char*)bases;
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads <= 0 ? 1 : n_threads, chunks / 65536 + 1));
+  if (T == 1) {
+    gf_host_pack_range(b, n_bases, 0, chunks, pk, iv);
+    return GF_OK;
+  }
+  std::vector<std::thread> th;
+  const int64_t per = ((chunks + T - 1) / T + 1) & ~(int64_t)1;  // (even: the AVX2 loop takes chunks in pairs)
+  for (int t = 0; t < T; ++t) {
+    const int64_t c0 = std::min<int64_t>((int64_t)t * per, chunks), c1 = std::min<int64_t>(c0 + per, chunks);
+    if (c0 < c1) th.emplace_back([=] { gf_host_pack_range(b, n_bases, c0, c1, pk, iv); });
+  }
+  for (auto& x : th) x.join();
   return GF_OK;
 }
 
@@ -1983,6 +2010,58 @@ int gf_stream_submit(gf_stream* s, const char* bases, const int64_t* offsets, in
     GF_HIP(hipMemcpyAsync(sl.d_off, offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, sl.st));
     int rc = gf_map_reads_device(s->ix, sl.d_bases + lead - b0, sl.d_off, n, (int32_t)std::max<int64_t>(maxlen, 1),
                                  sl.d_counts, sl.d_matches, (void*)sl.st);
+    if (rc != GF_OK) return rc;
+    rc = gf_compact_hits_device(s->ix, sl.d_counts, sl.d_matches, n, read_id_base, sl.d_hits, n, sl.d_total, sl.d_cws,
+                                (void*)sl.st);
+    if (rc != GF_OK) return rc;
+    GF_HIP(hipMemcpyAsync(sl.h_total, sl.d_total, 8, hipMemcpyDeviceToHost, sl.st));
+    GF_HIP(hipMemcpyAsync(sl.h_hits, sl.d_hits, (size_t)std::min(n, s->pin_cap) * sizeof(gf_hit), hipMemcpyDeviceToHost,
+                          sl.st));
+  } else {
+    *sl.h_total = 0;
+  }
+  GF_HIP(hipEventRecord(sl.done, sl.st));
+  sl.inflight = true;
+  s->head = (s->head + 1) % s->depth;
+  s->live += 1;
+  return GF_OK;
+}
+
+int gf_stream_submit_packed(gf_stream* s, const uint32_t* pk, const uint16_t* iv, const int64_t* offsets, int64_t n,
+                            int64_t read_id_base) {
+  if (!s || n < 0 || (n > 0 && !offsets)) return fail(GF_ERR_ARG, "bad argument");
+  if (n > s->max_reads) return fail(GF_ERR_CAPACITY, "pack has more reads than the stream was opened for");
+  if (s->live == s->depth) return fail(GF_ERR_CAPACITY, "every slot is in flight: collect a pack first");
+  int64_t maxlen = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t l = offsets[r + 1] - offsets[r];
+    if (l < 0) return fail(GF_ERR_ARG, "offsets must be non-decreasing");
+    maxlen = std::max(maxlen, l);
+  }
+  if (maxlen > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "a read exceeds GF_MAX_READ_LEN");
+  const int64_t b0 = n > 0 ? offsets[0] : 0, b1 = n > 0 ? offsets[n] : 0;
+  if (b0 < 0) return fail(GF_ERR_ARG, "negative offset");
+  if (b1 - b0 > s->max_bytes) return fail(GF_ERR_CAPACITY, "pack has more bases than the stream was opened for");
+  if (b1 > b0 && (!pk || !iv)) return fail(GF_ERR_ARG, "null packed stream");
+  DeviceGuard guard(s->ix->device);
+  gf_stream::Slot& sl = s->slots[(size_t)s->head];
+  sl.n = n;
+  if (n > 0) {
+    // chunks c0 .. c1-1 cover the pack's bases (+1: the kernels' staging reads one chunk past a tile's last);
+    // the slot's base area (max_bytes + 64 bytes) holds them: 6 bytes per chunk of 16 bases
+    const int64_t c0 = b0 >> 4, c1 = ((b1 + 15) >> 4) + 1, nc = c1 - c0;
+    uint32_t* d_pk = (uint32_t*)sl.d_bases;
+    uint16_t* d_iv = (uint16_t*)(sl.d_bases + (((size_t)nc * 4 + 15) & ~(size_t)15));
+    if ((((size_t)nc * 4 + 15) & ~(size_t)15) + (size_t)nc * 2 > (size_t)s->max_bytes + 64)
+      return fail(GF_ERR_CAPACITY, "pack has more bases than the stream was opened for");
+    GF_HIP(hipMemcpyAsync(d_pk, pk + c0, (size_t)(nc - 1) * 4, hipMemcpyHostToDevice, sl.st));
+    GF_HIP(hipMemcpyAsync(d_iv, iv + c0, (size_t)(nc - 1) * 2, hipMemcpyHostToDevice, sl.st));
+    GF_HIP(hipMemsetAsync(d_pk + (nc - 1), 0, 4, sl.st));       // the chunk past the end: nothing, all bad
+    GF_HIP(hipMemsetAsync(d_iv + (nc - 1), 0xFF, 2, sl.st));
+    GF_HIP(hipMemcpyAsync(sl.d_off, offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, sl.st));
+    // the device arrays start at chunk c0 of the host's stream: shift the pointers, the offsets stay as they are
+    int rc = gf_map_reads_packed_device(s->ix, d_pk - c0, d_iv - c0, sl.d_off, n, (int32_t)std::max<int64_t>(maxlen, 1),
+                                        sl.d_counts, sl.d_matches, (void*)sl.st);
     if (rc != GF_OK) return rc;
     rc = gf_compact_hits_device(s->ix, sl.d_counts, sl.d_matches, n, read_id_base, sl.d_hits, n, sl.d_total, sl.d_cws,
                                 (void*)sl.st);

@@ -46,6 +46,13 @@ class MapStream:
         n = offsets.size - 1
         _lib.check(_lib.lib().gf_stream_submit(self._h, bases.ctypes.data, offsets.ctypes.data, n, int(read_id_base)))
 
+    def submit_packed(self, pk: np.ndarray, iv: np.ndarray, offsets: np.ndarray, read_id_base: int = 0) -> None:
+        """The same pack in packed form (``pack_bases_host``): 0.375 bytes per base over the link instead of 1."""
+        assert pk.dtype == np.uint32 and iv.dtype == np.uint16 and offsets.dtype == np.int64 and offsets.flags.c_contiguous
+        n = offsets.size - 1
+        _lib.check(_lib.lib().gf_stream_submit_packed(self._h, pk.ctypes.data, iv.ctypes.data, offsets.ctypes.data, n,
+                                                      int(read_id_base)))
+
     def collect(self) -> np.ndarray:
         """Hit records (HIT_DTYPE) of the oldest pack in flight."""
         total = C.c_int64(0)
@@ -71,3 +78,14 @@ class MapStream:
             self.close()
         except Exception:
             pass
+
+
+def pack_bases_host(bases: np.ndarray, threads: int = 1, pinned: bool = False):
+    """gf_pack_bases_host: (pk uint32[chunks], iv uint16[chunks]) of an ASCII base buffer, on the host (no device
+    needed); ``pinned`` puts the result in pinned memory so that ``submit_packed`` copies asynchronously."""
+    assert bases.dtype == np.uint8 and bases.flags.c_contiguous
+    chunks = int(_lib.lib().gf_packed_chunks(bases.size))
+    pk = pinned_empty(chunks, np.uint32) if pinned else np.empty(chunks, dtype=np.uint32)
+    iv = pinned_empty(chunks, np.uint16) if pinned else np.empty(chunks, dtype=np.uint16)
+    _lib.check(_lib.lib().gf_pack_bases_host(bases.ctypes.data, bases.size, pk.ctypes.data, iv.ctypes.data, int(threads)))
+    return pk, iv

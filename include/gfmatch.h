@@ -192,6 +192,12 @@ int gf_pack_bases_device(const gf_index* idx, const void* d_bases, int64_t n_bas
 int gf_map_reads_packed_device(const gf_index* idx, const void* d_pk, const void* d_iv, const void* d_offsets, int64_t n,
                                int32_t max_read_len, void* d_counts, void* d_matches, void* stream);
 
+/* The same conversion on the HOST (AVX2 where the CPU has it), for hosts that ship their reads over the link: the
+ * packed form is 6 bytes per 16 bases where ASCII is 16, and the link — not the kernels — bounds a host-fed GPU.
+ * pk / iv: gf_packed_chunks(n_bases) elements each, the words gf_pack_bases_device would write; n_threads host
+ * threads (<= 0: one).  Needs no device. */
+int gf_pack_bases_host(const char* bases, int64_t n_bases, uint32_t* pk, uint16_t* iv, int32_t n_threads);
+
 /* Ordered compaction of the dense result (device): writes gf_hit records for the
  * reads with count 1..2, ascending read index, to d_hits (capacity hits_cap
  * records) and the total to *d_n_hits (int64 on device).  d_workspace must hold
@@ -380,6 +386,11 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
 typedef struct gf_stream gf_stream;
 int gf_stream_open(const gf_index* idx, int64_t max_reads, int64_t max_bytes, int32_t depth, gf_stream** out);
 int gf_stream_submit(gf_stream* s, const char* bases, const int64_t* offsets, int64_t n, int64_t read_id_base);
+/* The pack in packed form (gf_pack_bases_host): pk / iv are the packed stream of a base buffer, offsets (int64[n+1])
+ * count bases in that buffer as for gf_stream_submit; the chunks covering offsets[0] .. offsets[n] cross the link
+ * (0.375 bytes per base).  max_bytes of gf_stream_open bounds the pack's bases as before. */
+int gf_stream_submit_packed(gf_stream* s, const uint32_t* pk, const uint16_t* iv, const int64_t* offsets, int64_t n,
+                            int64_t read_id_base);
 int gf_stream_collect(gf_stream* s, gf_hit* out_hits, int64_t cap, int64_t* out_n);
 void gf_stream_close(gf_stream* s);
 /* pinned host memory for the buffers handed to gf_stream_submit / gf_map_reads* (hipHostMalloc) */

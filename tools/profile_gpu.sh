@@ -12,7 +12,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # BENCH_ARGS: extra bench.py arguments (e.g. "--config 2 --pairs 10000000" for IDX-C at 20 M reads);
 # PMC_SETS: "all" (default) or "traffic" (FETCH/WRITE/TCC only)
-BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-h2d ${BENCH_ARGS:-}"
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --profile-mode ${BENCH_ARGS:-}"
 PMC_SETS=${PMC_SETS:-all}
 echo "== kernel trace ==" 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.log 2>&1 || { echo trace failed; tail -20 $OUT/trace_bench.log; exit 1; }
