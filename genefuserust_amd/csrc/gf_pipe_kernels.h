@@ -732,6 +732,36 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt;
 }
 
+// ---- a block's chunk of entries through LDS (coalesced in, own entry out) ----
+template <int PW>
+__device__ __forceinline__ void gf_entries_to_lds(gf_u32x4* s_ent, const GfPipeEntryW<PW>* chunk, unsigned int cnt) {
+  constexpr int EW = GfPipeEntryW<PW>::EW, EWP = EW + 1;
+  const gf_u32x4* src = (const gf_u32x4*)chunk;
+#pragma unroll
+  for (int k = 0; k < EW; ++k) {
+    const unsigned int g = (unsigned int)k * 256u + threadIdx.x;
+    if (g < cnt * EW) s_ent[(g / EW) * EWP + g % EW] = src[g];
+  }
+}
+template <int PW>
+__device__ __forceinline__ void gf_entry_from_lds(const gf_u32x4* s_ent, uint32_t& r, uint32_t& v1v2,
+                                                  uint32_t (&m)[GfPipeEntryW<PW>::NT], uint32_t (&pk)[PW + 1]) {
+  constexpr int NT = GfPipeEntryW<PW>::NT, EW = GfPipeEntryW<PW>::EW, EWP = EW + 1;
+  uint32_t w[4 * EW];
+#pragma unroll
+  for (int j = 0; j < EW; ++j) {
+    const gf_u32x4 q = s_ent[threadIdx.x * EWP + j];
+    w[4 * j] = q.x; w[4 * j + 1] = q.y; w[4 * j + 2] = q.z; w[4 * j + 3] = q.w;
+  }
+  r = w[0];
+  v1v2 = w[1];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) m[k] = w[2 + k];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) pk[j] = w[2 + NT + j];
+  pk[PW] = 0;
+}
+
 // ---- K_filter / K_buckets: the undecided reads, in two dense passes ----
 // K_filter (thread per undecided read) asks the presence filter about every unverified
 // window, two windows per look-up (they share a 14-mer; L2 hits only): a window the filter
@@ -765,6 +795,11 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
   // its ODD pairs: those of the last part at once, the others in sweep 1 (launches for parts 0 .. nparts-2 over
   // what is left — a tenth of the background reads), whose last launch meets the bound again with every pair
   // asked and marks what still stands GF_ENTRY_FILTERED.  Half the look-ups of the form that asked every pair.
+  // The block's 256 entries of a round go in and out through LDS: a lane fetching its own 64-byte entry as four
+  // 16-byte loads touches a line per load (64 lanes, 64 lines, four times over), the block fetching the chunk as one
+  // contiguous run touches each line once — a third of this kernel's L2 requests were its entries (r03, §5).
+  constexpr int EW = GfPipeEntryW<PW>::EW, EWP = EW + 1;  // (+1 vector of padding per entry: LDS banks)
+  __shared__ gf_u32x4 s_ent[256 * EWP];
   __shared__ unsigned int s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
@@ -775,6 +810,9 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
   GfPipeEntryW<PW>* my_list = list_b + (int64_t)blockIdx.x * per_block;
   for (unsigned int t0 = 0; t0 < nb; t0 += 256) {
     const unsigned int t = t0 + threadIdx.x;
+    const unsigned int cnt = nb - t0 < 256u ? nb - t0 : 256u;
+    gf_entries_to_lds<PW>(s_ent, my_list + t0, cnt);
+    __syncthreads();
     bool alive = false;
     constexpr int NT = GfPipeEntryW<PW>::NT;
     uint32_t r = 0, v1v2 = 0, m[NT], pk[PW + 1];
@@ -782,7 +820,7 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
 #pragma unroll
     for (int k = 0; k < NT; ++k) m[k] = pp[k] = 0;
     if (t < nb) {
-      gf_entry_load<PW>(my_list + t, r, v1v2, m, pk);
+      gf_entry_from_lds<PW>(s_ent, r, v1v2, m, pk);
       const bool filtered = (v1v2 & GF_ENTRY_FILTERED) != 0;  // every window listed has been through the filter
       const int v1 = (int)(v1v2 & 0xFFu), v2 = (int)((v1v2 >> 8) & 0xFFu);
       const bool no_candidate = PW == 10 && !filtered && v1 == 0 && v2 == 0 && T.bloom_words != 0;
@@ -898,11 +936,38 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
       if (dead) counts[r] = 0;
       alive = !dead;
     }
-    __syncthreads();  // this chunk's entries are in registers: the compacted ones may overwrite them
+    const unsigned int base = s_cnt;  // (stable: the last appends were before the barrier above)
+    __syncthreads();  // this chunk's entries are in registers: the staging area and the list may be overwritten
     const unsigned int slot = gf_wave_append_lds(alive, &s_cnt);
-    if (alive) gf_entry_store<PW>(my_list + slot, r, v1v2, pp, pk);
+    if (alive) {
+      uint32_t w[4 * EW];
+      w[0] = r;
+      w[1] = v1v2;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) w[2 + k] = pp[k];
+#pragma unroll
+      for (int j = 0; j < PW; ++j) w[2 + NT + j] = pk[j];
+#pragma unroll
+      for (int j = 2 + NT + PW; j < 4 * EW; ++j) w[j] = 0;
+#pragma unroll
+      for (int j = 0; j < EW; ++j) {
+        gf_u32x4 q;
+        q.x = w[4 * j]; q.y = w[4 * j + 1]; q.z = w[4 * j + 2]; q.w = w[4 * j + 3];
+        s_ent[(slot - base) * EWP + j] = q;
+      }
+    }
+    __syncthreads();
+    {  // the survivors of the chunk, compacted, as one contiguous run behind the earlier ones (never beyond t0 + cnt)
+      const unsigned int n_alive = s_cnt - base;
+      gf_u32x4* dst = (gf_u32x4*)(my_list + base);
+#pragma unroll
+      for (int k = 0; k < EW; ++k) {
+        const unsigned int g = (unsigned int)k * 256u + threadIdx.x;
+        if (g < n_alive * EW) dst[g] = s_ent[(g / EW) * EWP + g % EW];
+      }
+    }
+    __syncthreads();  // the next chunk's loads overwrite the staging area
   }
-  __syncthreads();
   if (threadIdx.x == 0) blk_cnt2[blockIdx.x] = s_cnt;
 }
 
@@ -918,6 +983,8 @@ __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPip
   const unsigned int nb = blk_cnt2[blockIdx.x];
   const GfPipeEntryW<PW>* my_list = list_b + (int64_t)blockIdx.x * per_block;
   const unsigned int nb_round = (nb + 63u) & ~63u;  // whole waves stay in the loop for the ballot
+  // (no block barrier in this loop: a wave's probes take as long as its unluckiest lane, and fetching the entries
+  //  block-wide through LDS, as gf_k_probe_filter does, made every wave wait for the block's — 0.15 -> 0.29 ms, r03)
   for (unsigned int t = threadIdx.x; t < nb_round; t += blockDim.x) {
     bool to_full = false;
     uint32_t r = 0;

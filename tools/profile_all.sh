@@ -1,0 +1,19 @@
+#!/bin/bash
+# The round's counter measurements at the bench's own sizes (GPU box): configs 1, 2 (200 M reads) and 4, each through
+# tools/profile_gpu.sh (PMC_SETS=traffic) + tools/make_traffic.py; results under gpurun_out/prof_<tag>_cfg*/ and the
+# updated profiles/hbm_traffic.json copied to gpurun_out/.
+set -o pipefail
+TAG=${1:-r03}
+export PMC_SETS=traffic
+BENCH_ARGS="--calib" bash tools/profile_gpu.sh ${TAG}_cfg1 > gpurun_out/prof_${TAG}_cfg1.log 2>&1 || { tail -5 gpurun_out/prof_${TAG}_cfg1.log; exit 1; }
+python3 tools/make_traffic.py gpurun_out/prof_${TAG}_cfg1 IDX-D_20000000_150 profiles/${TAG}_cfg1_rocprofv3_summary.txt | tail -6
+echo "cfg1 done"
+PMC_SETS=min BENCH_ARGS="--config 2 --steps 3" bash tools/profile_gpu.sh ${TAG}_cfg2 > gpurun_out/prof_${TAG}_cfg2.log 2>&1 || { tail -5 gpurun_out/prof_${TAG}_cfg2.log; exit 1; }
+python3 tools/make_traffic.py gpurun_out/prof_${TAG}_cfg2 IDX-C_200000000_150 profiles/${TAG}_cfg2_rocprofv3_summary.txt | tail -6
+echo "cfg2 done"
+PMC_SETS=min BENCH_ARGS="--config 4 --steps 1 --warmup 1" bash tools/profile_gpu.sh ${TAG}_cfg4 > gpurun_out/prof_${TAG}_cfg4.log 2>&1 || { tail -5 gpurun_out/prof_${TAG}_cfg4.log; exit 1; }
+python3 tools/make_traffic.py gpurun_out/prof_${TAG}_cfg4 config4_50000000x16_150 profiles/${TAG}_cfg4_rocprofv3_summary.txt --per-step 2 | tail -14
+echo "cfg4 done"
+cp profiles/hbm_traffic.json gpurun_out/hbm_traffic_${TAG}.json
+# the raw per-dispatch CSVs are tens of MB per configuration: gpurun copies back 64 MiB at most
+find gpurun_out/prof_${TAG}_cfg* -name "*.csv" -size +512k -delete

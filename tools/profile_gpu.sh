@@ -11,7 +11,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # BENCH_ARGS: extra bench.py arguments (e.g. "--config 2 --pairs 10000000" for IDX-C at 20 M reads);
-# PMC_SETS: "all" (default) or "traffic" (FETCH/WRITE/TCC only)
+# PMC_SETS: "all" (default), "traffic" (FETCH/WRITE/TCC only) or "min" (three passes: bytes and L2 hits / misses)
 BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --profile-mode ${BENCH_ARGS:-}"
 PMC_SETS=${PMC_SETS:-all}
 echo "== kernel trace ==" 
@@ -21,6 +21,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $
 SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum"
       "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_32B_sum" "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum"
       "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum")
+if [ "$PMC_SETS" = "min" ]; then   # what tools/make_traffic.py needs, nothing else (the 200 M-read configuration)
+  SETS=("WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_32B_sum")
+fi
 if [ "$PMC_SETS" = "all" ]; then
   SETS+=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE")
 fi
