@@ -220,6 +220,12 @@ __device__ __forceinline__ uint32_t gf_window_mask(int nwin, int k) {
   return m >= 32 ? 0xFFFFFFFFu : (m <= 0 ? 0u : ((1u << m) - 1u));
 }
 
+// which forms of the filter the seeds ask before their bucket probe: 3 = the L2-resident one (2) and the one beyond the
+// L2 (1); 2 = only the former.  A look-up of a filter that does not live in the L2 is a miss like the bucket probe it
+// is meant to spare — and the probe names the diagonal (r03: IDX-C is bound by missed lines, §5).
+#ifndef GF_SEED_FILTER_MASK
+#define GF_SEED_FILTER_MASK 2u
+#endif
 #ifndef GF_FILTER_AUX
 #define GF_FILTER_AUX 0  // cache policy bits of the inline filter's buffer loads (experiments: 1 sc0, 2 nt, 16 sc1)
 #endif
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // Seed 0 first — filter, then its bucket: most reads that have a candidate diagonal get it
           // here, for one filter line into the L1 instead of four (the kernel is bound by those line
           // fills); the other three seeds are asked about only by the reads still without one.
-          if (T.bloom_in_l2) {
+          if (T.bloom_in_l2 & GF_SEED_FILTER_MASK) {
             const uint32_t h2 = GF_BLOOM_HASH((key[0] >> 4));
             const uint32_t fb = GF_BLOOM_BITS(h2);
             if ((T.bloom[GF_BLOOM_WORD(h2, T.bloom_words)] & fb) != fb) {
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             if (ty == GF_TYPE_UNIQUE) K = val & GF_LIN_MASK;
             else if (ty != GF_TYPE_DUPES) kill[0] |= 1u;
           }
-          if (K == GF_NONE_LIN && T.bloom_in_l2) {
+          if (K == GF_NONE_LIN && (T.bloom_in_l2 & GF_SEED_FILTER_MASK)) {
             uint32_t fw[4], fb[4];
 #pragma unroll
             for (int s = 1; s < 4; ++s) {

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--check", type=int, default=3000)
+    ap.add_argument("--profile-mode", action="store_true", help="the timed stages only (for rocprofv3): no host tail, no oracle")
     a = ap.parse_args()
     from genefuserust_amd import FusionMapper, Indexer, synth
     from genefuserust_amd.fastq import fastq_cut_device
@@ -50,6 +51,9 @@ def main():
                          a.steps, a.warmup)
     rec, hb, hq, tot = res.download()
     assert tot["overflow"] == 0, tot
+    if a.profile_mode:
+        print(json.dumps({"stage_ms": {"fastq_cut_R1": ms_cut1, "fastq_cut_R2": ms_cut2, "scan_pairs_device": ms_scan}, "totals": tot}))
+        return 0
     fm = FusionMapper(ix)
     t0 = time.perf_counter()
     done = finish_pair_hits(fm, rec, hb, hq)
@@ -92,11 +96,32 @@ def main():
     k = len(ids)
     total = ms_cut1 + ms_cut2 + ms_scan
     text_bytes = int(t1.numel() + t2.numel())
+    # roofline per stage: counter-measured bytes (tools/profile_pairs.sh -> profiles/frontend_traffic.json, calibrated as
+    # in DESIGN.md 5: read = 32 B x TCC_EA0_RDREQ_DRAM_32B, written = WRITE_SIZE) over this run's stage time, and the
+    # stage's algorithmic in + out bytes (text in; bases, qualities, offsets out / records in, hit records out)
+    roof = {}
+    try:
+        ft = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "frontend_traffic.json")))
+        scale = n / ft["pairs"]
+        rec_bytes = int(t1.numel()) // n
+        algo = {"fastq_cut": rec_bytes * n + 2 * L * n + 8 * (n + 1),
+                "scan_pairs_device": 2 * (2 * L * n + 8 * (n + 1)) + 64 * int(tot["hits"]) + 2 * int(tot["hit_bytes"])}
+        for st, ms in (("fastq_cut", 0.5 * (ms_cut1 + ms_cut2)), ("scan_pairs_device", ms_scan)):
+            e = ft["stages"][st]
+            b = (e["read_bytes"] + e["write_bytes"]) * scale
+            roof[st] = {"bound": "hbm", "ms": ms, "traffic": int(b), "achieved": b / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
+                        "frac": b / ms / 1e6 / 8000.0, "frac_of_copy_ceiling_6290": b / ms / 1e6 / 6290.0,
+                        "algorithmic_bytes": algo[st], "algorithmic_GBps": algo[st] / ms / 1e6,
+                        "algorithmic_frac": algo[st] / ms / 1e6 / 8000.0,
+                        "kernel_ms_when_profiled": e["kernel_ms"], "traffic_source": "profiles/frontend_traffic.json (%s)" % ft.get("source_dir")}
+    except Exception as e:  # noqa: BLE001
+        roof = {"error": "%s: %s" % (type(e).__name__, e)}
     print(json.dumps({
         "metric": "read pairs per second from FASTQ text in HBM to the hit list (records + scan_pair_end policy in one device call)",
         "value": n / (total / 1e3), "unit": "pairs/s", "pairs": n, "read_len": L, "index_shape": a.shape,
         "stage_ms": {"fastq_cut_R1": round(ms_cut1, 3), "fastq_cut_R2": round(ms_cut2, 3), "scan_pairs_device": round(ms_scan, 3)},
         "scan_pairs_only_pairs_per_s": n / (ms_scan / 1e3),
+        "roofline": roof,
         "totals": tot, "junction_pairs": int((kinds == 2).sum()),
         "host_tail": {"hits": len(done), "seconds": round(tail_s, 4), "hits_per_s": len(done) / tail_s if tail_s else None,
                       "note": "finish_pair_hits: gf_pair_hits_finish + one Python ReadMatch object per hit",
