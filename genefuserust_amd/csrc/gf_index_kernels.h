@@ -35,6 +35,30 @@ struct GfGenes {
 
 enum { GF_MODE_COUNT = 0, GF_MODE_FILL = 1 };
 
+// indexer.rs:159: the gene slices are upper-cased before they are indexed (ASCII letters; the FASTA reader keeps
+// letters, '-' and '*' only).  In place on the device copy, 16 bytes per thread and step.
+__global__ __launch_bounds__(256) void gf_k_upper_inplace(uint8_t* __restrict__ p, unsigned long long n_vec) {
+  uint4* v = (uint4*)p;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (unsigned long long)gridDim.x * 256) {
+    uint4 q = v[i];
+    uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t x = w[k], y = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        uint32_t ch = (x >> (8 * b)) & 0xFFu;
+        if (ch - 'a' < 26u) ch -= 32u;
+        y |= ch << (8 * b);
+      }
+      any |= y != x;
+      w[k] = y;
+    }
+    if (any) v[i] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 __device__ __forceinline__ uint64_t gf_atomic_load64(uint64_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

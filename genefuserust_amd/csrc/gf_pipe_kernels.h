@@ -780,14 +780,11 @@ __device__ __forceinline__ void gf_entry_from_lds(const gf_u32x4* s_ent, uint32_
 // v1 + h + left < 20 or v2 + h + left < 10 -> [].  Survivors go to the exact kernel.
 // (One kernel doing both kept every wave in the bucket loop for as long as its unluckiest
 // lane: most of its instructions were executed for a handful of lanes.)
-#define GF_ENTRY_ROUND1 0x40000000u  // in w[1]: a read without a candidate diagonal that outlived round 0 of the look-ups below
-
 template <int PW>
 __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW<PW>* __restrict__ list_b,
                                                          const unsigned int* __restrict__ blk_cnt, int64_t per_block,
                                                          uint8_t* __restrict__ counts,
-                                                         unsigned int* __restrict__ blk_cnt2, int phase, int nparts,
-                                                         int sweep) {
+                                                         unsigned int* __restrict__ blk_cnt2, int phase, int nparts) {
   // nparts 1: the whole filter in one pass.  A filter larger than an XCD's L2 is asked in nparts
   // passes instead, each touching one part of its words (which then stays in the L2): phase p
   // asks the look-ups that fall in part p and leaves the others standing.
@@ -795,12 +792,11 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
   // Reads WITH a candidate diagonal (v1 > 0) ask every window the verification left open, part by part, and die
   // by  v1 + P < 20 or v2 + P < 10;  after the last part they are marked GF_ENTRY_FILTERED.
   // Reads WITHOUT one (background, mostly; they come here when the filter is too large for seed+verify to ask it
-  // itself) go by the bound of gf_table.h, like seed+verify's inline pass (r03): sweep 0 asks the EVEN pairs of
-  // windows, part by part; after its last part the bound decides — at most 12 votes for a 150-base read whose
-  // even pairs are all ruled out, +3 per false positive, 20 needed.  A survivor is marked GF_ENTRY_ROUND1 and asks
-  // its ODD pairs: those of the last part at once, the others in sweep 1 (launches for parts 0 .. nparts-2 over
-  // what is left — a tenth of the background reads), whose last launch meets the bound again with every pair
-  // asked and marks what still stands GF_ENTRY_FILTERED.  Half the look-ups of the form that asked every pair.
+  // itself) go by the bound of gf_table.h (r03): part by part every pair of windows is asked, and after the last part
+  // the bound decides — far stronger than "fewer than 20 windows left": the bucket pass behind sees half the reads.
+  // (Asking only the even pairs first, as seed+verify does, needs a third launch over the survivors for a filter
+  // in two parts, and a launch over the list costs 0.7 ms whatever it asks: 1.85 ms against 1.58)
+  // With the whole filter in one part the even pairs go first and the bound may stop the read before the odd ones.
   // The block's 256 entries of a round go in and out through LDS: a lane fetching its own 64-byte entry as four
   // 16-byte loads touches a line per load (64 lanes, 64 lines, four times over), the block fetching the chunk as one
   // contiguous run touches each line once — a third of this kernel's L2 requests were its entries (r03, §5).
@@ -812,7 +808,7 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
   const unsigned int nb = blk_cnt[blockIdx.x];
   const uint32_t part_words = (T.bloom_words + (uint32_t)nparts - 1) / (uint32_t)nparts;
   const uint32_t part_lo = (uint32_t)phase * part_words, part_hi = part_lo + part_words;
-  const bool last_part = sweep == 0 ? phase == nparts - 1 : phase == nparts - 2;  // this launch completes its sweep
+  const bool last_part = phase == nparts - 1;
   GfPipeEntryW<PW>* my_list = list_b + (int64_t)blockIdx.x * per_block;
   for (unsigned int t0 = 0; t0 < nb; t0 += 256) {
     const unsigned int t = t0 + threadIdx.x;
@@ -864,31 +860,25 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
           for (int k = 0; k < NT; ++k) x[k] = (m[k] | (m[k] >> 1)) & 0x55555555u;
           return gf_vote_bound_pairs<4 * PW - 3>(x);
         };
-        const bool round1 = (v1v2 & GF_ENTRY_ROUND1) != 0;
-        if (sweep == 0) {   // (a sweep-0 launch never meets a ROUND1 entry: they are made by its last launch)
+        if (nparts == 1) {   // the whole filter at hand: even pairs, the bound, and only then the odd ones
           ask(0u);
-          if (last_part) {
+          dead = bound() < GF_MAJOR_KEYS / 2;
+          if (!dead) {
+            ask(1u);
             dead = bound() < GF_MAJOR_KEYS / 2;
-            if (!dead) {
-              ask(1u);      // the odd pairs of this part at once
-              if (nparts == 1) {
-                dead = bound() < GF_MAJOR_KEYS / 2;
-                v1v2 |= GF_ENTRY_FILTERED;
-              } else {
-                v1v2 |= GF_ENTRY_ROUND1;
-              }
-            }
           }
-        } else if (round1) {
+          v1v2 |= GF_ENTRY_FILTERED;
+        } else {             // part by part: every pair of this part; the bound once every part has been asked
+          ask(0u);
           ask(1u);
           if (last_part) {
             dead = bound() < GF_MAJOR_KEYS / 2;
-            v1v2 = (v1v2 & ~GF_ENTRY_ROUND1) | GF_ENTRY_FILTERED;
+            v1v2 |= GF_ENTRY_FILTERED;
           }
         }
 #pragma unroll
         for (int k = 0; k < NT; ++k) pp[k] = m[k];
-      } else if (T.bloom_words && sweep == 0) {
+      } else if (T.bloom_words) {
         int npos = 0, rem = 0;  // not ruled out / not asked yet
 #pragma unroll
         for (int k = 0; k < NT; ++k) rem += __popc(m[k]);
@@ -937,7 +927,7 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
         int left = 0;
 #pragma unroll
         for (int k = 0; k < NT; ++k) left += __popc(m[k]);
-        dead = !filtered && sweep == 0 && ((v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2));
+        dead = !filtered && ((v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2));
       }
       if (dead) counts[r] = 0;
       alive = !dead;

@@ -195,7 +195,16 @@ struct gf_index {
   // first pass for reads <= 256 bases: 0 = flat pipeline (pack, seed+verify, probe, exact
   // kernel on survivors), 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify
   int map_variant = 0;
-  std::vector<std::string> fusion_seq;  // Indexer.m_fusion_seq (indexer.rs:77)
+  // Indexer.m_fusion_seq (indexer.rs:77, :170): the upper-cased gene slices.  The device keeps them (d_cat, one
+  // concatenation: the build's own input, upper-cased there); the host copy of a gene is fetched on first use —
+  // in multi-CSV mode an index lives for one pass over the reads and only the genes of its few hits are ever asked for
+  mutable std::vector<std::string> fusion_seq;
+  mutable std::vector<uint8_t> fusion_ready;
+  mutable std::mutex fusion_mu;
+  std::vector<uint32_t> gene_off_h, gene_len_h;
+  uint8_t* d_cat = nullptr;
+  uint32_t* d_gene_off = nullptr;
+  int ensure_fusion(int32_t c) const;
   gf_index_info info{};
   // profiling
   bool profiling = false;
@@ -224,6 +233,8 @@ struct gf_index {
     block_free(device, d_gene_len);
     block_free(device, d_gdu);
     block_free(device, d_bloom);
+    block_free(device, d_cat);
+    block_free(device, d_gene_off);
     if (d_gene_rev) (void)hipFree(d_gene_rev);
     free_lanes();
     if (have_events) {
@@ -404,15 +415,12 @@ static int launch_flat(const gf_index* idx, const GfTable& T, hipStream_t st, co
   int nparts = T.bloom_in_l2 == 1 ? 2 : 1;
   if (parts_env >= 1 && parts_env <= 8 && T.bloom_in_l2 == 1) nparts = parts_env;
   unsigned int *cnt_in = w.blk_cnt, *cnt_out = w.blk_cnt2;
-  // sweep 0: every part once; sweep 1 (reads of up to 160 bases, more than one part): the odd window pairs of the
-  // reads without a candidate that outlived sweep 0, for the parts before the last (gf_k_probe_filter)
-  for (int sweep = 0; sweep < (nparts > 1 && PW == 10 ? 2 : 1); ++sweep)
-    for (int ph = 0; ph < (sweep == 0 ? nparts : nparts - 1); ++ph) {
-      hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(p.nblk), dim3(256), 0, st, T,
-                         (GfPipeEntryW<PW>*)w.list_b, (const unsigned int*)cnt_in, p.per_block, counts, cnt_out, ph,
-                         nparts, sweep);
-      std::swap(cnt_in, cnt_out);
-    }
+  for (int ph = 0; ph < nparts; ++ph) {
+    hipLaunchKernelGGL((gf_k_probe_filter<PW>), dim3(p.nblk), dim3(256), 0, st, T,
+                       (GfPipeEntryW<PW>*)w.list_b, (const unsigned int*)cnt_in, p.per_block, counts, cnt_out, ph,
+                       nparts);
+    std::swap(cnt_in, cnt_out);
+  }
   const unsigned int* survivors = cnt_in;  // (the last launch's output)
   if (ev) GF_HIP(hipEventRecord(ev[2], st));
   hipLaunchKernelGGL((gf_k_probe_buckets<PW>), dim3(p.nblk), dim3(256), 0, st, T,
@@ -496,26 +504,62 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   }
   gene_off[(size_t)n_genes] = (uint32_t)total;
 
-  // upper-cased slices (Indexer.m_fusion_seq) and their concatenation for the device, gene by gene on a few
-  // host threads: in multi-CSV mode this runs once per CSV, 15 MB for a cancer-sized gene set
+  ix->fusion_ready.assign((size_t)n_genes, 0);
+  ix->gene_off_h = gene_off;
+  ix->gene_len_h.assign(glen.begin(), glen.begin() + n_genes);
+
+  // 8 slots per bucket, about 4 keys per bucket on average
+  uint64_t sites_per_bucket = 4;
+  if (const char* e = getenv("GF_SITES_PER_BUCKET")) sites_per_bucket = (uint64_t)std::max(1, std::min(7, atoi(e)));  // experiments
+  uint64_t nb64 = std::max<uint64_t>(16, (site_bound + sites_per_bucket - 1) / sites_per_bucket);
+  if (nb64 > 0x7FFFFFFFull) return fail(GF_ERR_CAPACITY, "table too large");
+  const uint32_t nbuckets = (uint32_t)nb64;
+  const uint64_t nslots = (uint64_t)nbuckets * GF_SLOTS_PER_BUCKET;
   const uint32_t ntiles = (uint32_t)((total + GF_TILE_BASES - 1) / GF_TILE_BASES);
   const size_t cat_bytes = (size_t)ntiles * GF_TILE_BASES + 64;
-  std::unique_ptr<uint8_t[]> cat_mem(new uint8_t[cat_bytes]);  // (not zero-filled: every byte is written below)
-  struct { uint8_t* p; uint8_t* data() const { return p; } } cat{cat_mem.get()};
+
+  // Device blocks first, and the clears queued at once: they run while the host gathers the slices (r03: the host
+  // third of a rebuild — upper-casing two copies of every gene, a pageable 15 MB copy, the clears behind them — was
+  // 0.96 of 3.7 ms per cancer-shaped gene set).
+  struct { uint8_t*& p; } d_cat{ix->d_cat};
+  struct { uint32_t*& p; } d_goff{ix->d_gene_off};
+  DevBuf<unsigned long long> d_stats;
+  GF_HIP(block_alloc(dev, (void**)&ix->d_cat, cat_bytes));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_gene_off, ((size_t)n_genes + 1) * sizeof(uint32_t)));
+  GF_HIP(d_stats.alloc(8));
+  // both strands of the genes in site-code space + per-site uniqueness bits (diagonal
+  // verification of the mapping kernel); padded so that a 256-base read hanging over
+  // either end of the space stays inside the arrays
+  const size_t gd_words = (size_t)(lin_cursor / 16) + 64;
+  GF_HIP(block_alloc(dev, (void**)&ix->d_gdu, 2 * gd_words * sizeof(uint32_t)));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_slots, nslots * sizeof(uint64_t)));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_lin_base, lin_base.size() * sizeof(uint32_t)));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_lin_hi, lin_hi.size() * sizeof(uint32_t)));
+  GF_HIP(block_alloc(dev, (void**)&ix->d_gene_len, glen.size() * sizeof(uint32_t)));
+  GF_HIP(hipMemsetAsync(ix->d_gdu, 0, 2 * gd_words * sizeof(uint32_t), 0));
+  GF_HIP(hipMemsetAsync(ix->d_slots, 0, nslots * sizeof(uint64_t), 0));
+  GF_HIP(hipMemsetAsync(d_stats.p, 0, 8 * sizeof(unsigned long long), 0));
+
+  // The raw slices and the four small arrays into ONE pinned staging block (kept by the process, grow-only), a few
+  // host threads copying; then asynchronous copies to the device, where the bytes are upper-cased in place
+  // (indexer.rs:159).  The staging block is the process's: builds take turns at it.
+  static std::mutex stage_mu;
+  static uint8_t* stage = nullptr;
+  static size_t stage_bytes = 0;
+  std::unique_lock<std::mutex> stage_lock(stage_mu);
+  struct StageDrain { ~StageDrain() { (void)hipDeviceSynchronize(); } } stage_drain;  // copies out of the block are done before the next build may write it
+  const size_t meta_words = ((size_t)n_genes + 1) + 3 * lin_base.size();
+  const size_t need_stage = cat_bytes + meta_words * sizeof(uint32_t) + 64;
+  if (stage_bytes < need_stage) {
+    if (stage) (void)hipHostFree(stage);
+    stage = nullptr;
+    stage_bytes = 0;
+    GF_HIP(hipHostMalloc((void**)&stage, need_stage + need_stage / 4, hipHostMallocDefault));
+    stage_bytes = need_stage + need_stage / 4;
+  }
   {
     auto prep = [&](int32_t c) {
-      const size_t len = glen[(size_t)c];
-      std::string& s = ix->fusion_seq[(size_t)c];
-      s.resize(len);
-      const unsigned char* src = (const unsigned char*)gene_seqs[c];
-      unsigned char* d1 = (unsigned char*)&s[0];
-      unsigned char* d2 = cat.data() + gene_off[(size_t)c];
-      for (size_t k = 0; k < len; ++k) {
-        const unsigned char ch = src[k];
-        const unsigned char up = (unsigned char)(ch - ((unsigned char)(ch - 'a') < 26u ? 32 : 0));  // indexer.rs:159
-        d1[k] = up;
-        d2[k] = up;
-      }
+      if (glen[(size_t)c]) memcpy(stage + gene_off[(size_t)c], gene_seqs[c], glen[(size_t)c]);
     };
     const int T = (int)std::min<uint64_t>(8, std::max<uint64_t>(1, total >> 20));  // a thread per MB, at most 8
     if (T <= 1) {
@@ -529,41 +573,24 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
         });
       for (auto& x : th) x.join();
     }
-    memset(cat.data() + total, 0, cat_bytes - total);
+    memset(stage + total, 0, cat_bytes - total);
   }
-
-  lap("host: slices, upper case, concatenation");
-  // 8 slots per bucket, about 4 keys per bucket on average
-  uint64_t sites_per_bucket = 4;
-  if (const char* e = getenv("GF_SITES_PER_BUCKET")) sites_per_bucket = (uint64_t)std::max(1, std::min(7, atoi(e)));  // experiments
-  uint64_t nb64 = std::max<uint64_t>(16, (site_bound + sites_per_bucket - 1) / sites_per_bucket);
-  if (nb64 > 0x7FFFFFFFull) return fail(GF_ERR_CAPACITY, "table too large");
-  const uint32_t nbuckets = (uint32_t)nb64;
-  const uint64_t nslots = (uint64_t)nbuckets * GF_SLOTS_PER_BUCKET;
-
-  struct CatBlock { int dev; uint8_t* p = nullptr; ~CatBlock() { if (p) { (void)hipDeviceSynchronize(); block_free(dev, p); } } } d_cat{dev};
-  DevBuf<uint32_t> d_goff;
-  DevBuf<unsigned long long> d_stats;
-  GF_HIP(block_alloc(dev, (void**)&d_cat.p, cat_bytes));
-  GF_HIP(d_goff.alloc((size_t)n_genes + 1));
-  GF_HIP(d_stats.alloc(8));
-  // both strands of the genes in site-code space + per-site uniqueness bits (diagonal
-  // verification of the mapping kernel); padded so that a 256-base read hanging over
-  // either end of the space stays inside the arrays
-  const size_t gd_words = (size_t)(lin_cursor / 16) + 64;
-  GF_HIP(block_alloc(dev, (void**)&ix->d_gdu, 2 * gd_words * sizeof(uint32_t)));
-  GF_HIP(hipMemset(ix->d_gdu, 0, 2 * gd_words * sizeof(uint32_t)));
-  GF_HIP(block_alloc(dev, (void**)&ix->d_slots, nslots * sizeof(uint64_t)));
-  GF_HIP(block_alloc(dev, (void**)&ix->d_lin_base, lin_base.size() * sizeof(uint32_t)));
-  GF_HIP(block_alloc(dev, (void**)&ix->d_lin_hi, lin_hi.size() * sizeof(uint32_t)));
-  GF_HIP(block_alloc(dev, (void**)&ix->d_gene_len, glen.size() * sizeof(uint32_t)));
-  GF_HIP(hipMemset(ix->d_slots, 0, nslots * sizeof(uint64_t)));
-  GF_HIP(hipMemset(d_stats.p, 0, 8 * sizeof(unsigned long long)));
-  GF_HIP(hipMemcpy(d_cat.p, cat.data(), cat_bytes, hipMemcpyHostToDevice));
-  GF_HIP(hipMemcpy(d_goff.p, gene_off.data(), gene_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  GF_HIP(hipMemcpy(ix->d_lin_base, lin_base.data(), lin_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  GF_HIP(hipMemcpy(ix->d_lin_hi, lin_hi.data(), lin_hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  GF_HIP(hipMemcpy(ix->d_gene_len, glen.data(), glen.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  uint32_t* meta = (uint32_t*)(stage + ((cat_bytes + 63) & ~(size_t)63));
+  uint32_t* m_goff = meta; uint32_t* m_lb = m_goff + ((size_t)n_genes + 1);
+  uint32_t* m_lh = m_lb + lin_base.size(); uint32_t* m_gl = m_lh + lin_base.size();
+  memcpy(m_goff, gene_off.data(), gene_off.size() * sizeof(uint32_t));
+  memcpy(m_lb, lin_base.data(), lin_base.size() * sizeof(uint32_t));
+  memcpy(m_lh, lin_hi.data(), lin_hi.size() * sizeof(uint32_t));
+  memcpy(m_gl, glen.data(), glen.size() * sizeof(uint32_t));
+  lap("host: slices into the pinned block (clears queued)");
+  GF_HIP(hipMemcpyAsync(d_cat.p, stage, cat_bytes, hipMemcpyHostToDevice, 0));
+  GF_HIP(hipMemcpyAsync(d_goff.p, m_goff, gene_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, 0));
+  GF_HIP(hipMemcpyAsync(ix->d_lin_base, m_lb, lin_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, 0));
+  GF_HIP(hipMemcpyAsync(ix->d_lin_hi, m_lh, lin_hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice, 0));
+  GF_HIP(hipMemcpyAsync(ix->d_gene_len, m_gl, glen.size() * sizeof(uint32_t), hipMemcpyHostToDevice, 0));
+  hipLaunchKernelGGL(gf_k_upper_inplace, dim3((unsigned)std::min<size_t>((cat_bytes / 16 + 255) / 256, 4096)), dim3(256), 0, 0,
+                     d_cat.p, (unsigned long long)(cat_bytes / 16));
+  GF_HIP(hipGetLastError());
 
   lap("alloc, memset, copies in");
   GfGenes G;
@@ -731,8 +758,25 @@ int gf_index_info_get(const gf_index* idx, gf_index_info* out) {
   return GF_OK;
 }
 
+// Indexer.m_fusion_seq[c] on the host: fetched from the device's upper-cased copy on first use
+int gf_index::ensure_fusion(int32_t c) const {
+  if (c < 0 || (size_t)c >= fusion_seq.size()) return fail(GF_ERR_ARG, "bad contig");
+  std::lock_guard<std::mutex> g(fusion_mu);
+  if (fusion_ready[(size_t)c]) return GF_OK;
+  std::string& s = fusion_seq[(size_t)c];
+  s.resize(gene_len_h[(size_t)c]);
+  if (!s.empty()) {
+    DeviceGuard guard(device);
+    GF_HIP(hipMemcpy(&s[0], d_cat + gene_off_h[(size_t)c], s.size(), hipMemcpyDeviceToHost));
+  }
+  fusion_ready[(size_t)c] = 1;
+  return GF_OK;
+}
+
 int64_t gf_index_fusion_seq(const gf_index* idx, int32_t contig, char* out, int64_t cap) {
   if (!idx || contig < 0 || (size_t)contig >= idx->fusion_seq.size()) return fail(GF_ERR_ARG, "bad contig");
+  if (!out || cap <= 0) return (int64_t)idx->gene_len_h[(size_t)contig];  // (the length alone needs no copy)
+  if (int rc = idx->ensure_fusion(contig)) return rc;
   const std::string& s = idx->fusion_seq[(size_t)contig];
   if (out && cap > 0) memcpy(out, s.data(), (size_t)std::min<int64_t>(cap, (int64_t)s.size()));
   return (int64_t)s.size();
@@ -1483,12 +1527,18 @@ int gf_pair_hits_finish(const gf_index* idx, const gf_pair_hit* hits, int64_t n,
   if (n == 0) return GF_OK;
   if (!hits || !out || !out_status || (hit_bytes > 0 && !hit_bases)) return fail(GF_ERR_ARG, "null argument");
   const size_t ng = idx->fusion_seq.size();
-  std::vector<const char*> fp(ng);
+  std::vector<const char*> fp(ng, nullptr);
   std::vector<int64_t> fl(ng);
-  for (size_t c = 0; c < ng; ++c) {
-    fp[c] = idx->fusion_seq[c].data();
-    fl[c] = (int64_t)idx->fusion_seq[c].size();
-  }
+  for (size_t c = 0; c < ng; ++c) fl[c] = (int64_t)idx->gene_len_h[c];
+  for (int64_t k = 0; k < n; ++k)   // the genes the records name (the only ones make_match looks at): fetched once
+    for (int e = 0; e < 2; ++e) {
+      const int32_t c = hits[k].m[e].contig;
+      if (c < 0 || (size_t)c >= ng) return fail(GF_ERR_ARG, "contig out of range");
+      if (!fp[(size_t)c]) {
+        if (int rc = idx->ensure_fusion(c)) return rc;
+        fp[(size_t)c] = idx->fusion_seq[(size_t)c].data();
+      }
+    }
   for (int64_t k = 0; k < n; ++k)
     if (hits[k].seq_offset < 0 || hits[k].read_len < 0 || hits[k].seq_offset + hits[k].read_len > hit_bytes)
       return fail(GF_ERR_ARG, "a record's read lies outside hit_bases");
@@ -1526,11 +1576,15 @@ int gf_pair_hits_finish(const gf_index* idx, const gf_pair_hit* hits, int64_t n,
 int gf_index_fusion_map_read(const gf_index* idx, const uint8_t* gene_reversed, const char* seq, int64_t len,
                              const gf_seqmatch* mapping, int32_t n_mapping, gf_readmatch* out) {
   if (!idx) return fail(GF_ERR_ARG, "null index");
-  std::vector<const char*> p(idx->fusion_seq.size());
+  std::vector<const char*> p(idx->fusion_seq.size(), nullptr);
   std::vector<int64_t> l(idx->fusion_seq.size());
-  for (size_t c = 0; c < p.size(); ++c) {
-    p[c] = idx->fusion_seq[c].data();
-    l[c] = (int64_t)idx->fusion_seq[c].size();
+  for (size_t c = 0; c < p.size(); ++c) l[c] = (int64_t)idx->gene_len_h[c];
+  for (int32_t k = 0; k < n_mapping && k < 2; ++k) {   // (make_match reads the genes of the two segments only)
+    const int32_t c = mapping ? mapping[k].contig : -1;
+    if (c >= 0 && (size_t)c < p.size()) {
+      if (int rc = idx->ensure_fusion(c)) return rc;
+      p[(size_t)c] = idx->fusion_seq[(size_t)c].data();
+    }
   }
   return gf_fusion_map_read(p.data(), l.data(), (int32_t)p.size(), gene_reversed, seq, len, mapping, n_mapping, out);
 }
