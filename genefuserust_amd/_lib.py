@@ -165,6 +165,8 @@ def lib() -> C.CDLL:
     L.gf_index_set_gene_reversed.restype = C.c_int
     L.gf_pair_hits_finish.argtypes = [vp, vp, i64, vp, i64, vp, vp, i32]
     L.gf_pair_hits_finish.restype = C.c_int
+    L.gf_pair_hits_finish_device.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
+    L.gf_pair_hits_finish_device.restype = C.c_int
     L.gf_scan_pairs_retry_capacity.argtypes = [i64]
     L.gf_scan_pairs_retry_capacity.restype = i64
     L.gf_scan_pairs_device.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, i32, i64, i64, vp, i64, vp, vp, i64, vp, vp]

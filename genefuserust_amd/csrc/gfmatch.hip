@@ -30,6 +30,7 @@
 #include "gf_host_pack.h"
 #include "gf_pipe_kernels.h"
 #include "gf_pair_kernels.h"
+#include "gf_tail_kernels.h"
 #include "gf_table.h"
 
 static_assert(sizeof(gf_seqmatch) == 16, "gf_seqmatch layout");
@@ -1570,6 +1571,21 @@ int gf_pair_hits_finish(const gf_index* idx, const gf_pair_hit* hits, int64_t n,
     for (auto& x : th) x.join();
   }
   if (err.load() != GF_OK) return fail(err.load(), err_msg);
+  return GF_OK;
+}
+
+int gf_pair_hits_finish_device(const gf_index* idx, const void* d_hits, const void* d_totals, int64_t hits_cap,
+                               const void* d_hit_bases, void* d_out, void* d_status, void* stream) {
+  if (!idx || hits_cap < 0) return fail(GF_ERR_ARG, "null index or negative capacity");
+  if (hits_cap == 0) return GF_OK;
+  if (!d_hits || !d_totals || !d_hit_bases || !d_out || !d_status) return fail(GF_ERR_ARG, "null device pointer");
+  DeviceGuard guard(idx->device);
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((2 * hits_cap + 3) / 4, (int64_t)idx->n_cus * 8));
+  hipLaunchKernelGGL(gf_k_pair_hits_finish, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const gf_pair_hit*)d_hits,
+                     (const int64_t*)d_totals, hits_cap, (const uint8_t*)d_hit_bases, (const uint8_t*)idx->d_cat,
+                     (const uint32_t*)idx->d_gene_off, (const uint32_t*)idx->d_gene_len, idx->table.n_genes,
+                     (gf_readmatch*)d_out, (int32_t*)d_status);
+  GF_HIP(hipGetLastError());
   return GF_OK;
 }
 

@@ -149,6 +149,21 @@ def scan_pairs_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_qual
     return PairScan(hits, hb, hq, totals)
 
 
+def finish_pair_hits_device(indexer: Indexer, scan: "PairScan", stream=None):
+    """The tail on the device (gf_pair_hits_finish_device): make_match + calc_distance for the records of a pair scan
+    while they are still in HBM.  Returns (readmatch uint8[cap, 28] tensor, status int32[cap] tensor); rows beyond
+    totals[0] are untouched.  Asynchronous."""
+    import torch
+    dev = scan.hits.device
+    cap = int(scan.hits.shape[0])
+    out = torch.zeros((max(cap, 1), _lib.READMATCH_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    status = torch.zeros(max(cap, 1), dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    _lib.check(_lib.lib().gf_pair_hits_finish_device(indexer._handle(), scan.hits.data_ptr(), scan.totals.data_ptr(), cap,
+                                                     scan.bases.data_ptr(), out.data_ptr(), status.data_ptr(), st))
+    return out, status
+
+
 def finish_pair_hits(mapper: FusionMapper, rec: np.ndarray, bases: bytes, quals: bytes,
                      threads: int = 8) -> List[Tuple[int, ReadMatch]]:
     """The host-side tail for the records of a pair scan: FusionMapper::make_match + calc_distance

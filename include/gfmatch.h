@@ -360,6 +360,13 @@ int gf_index_set_gene_reversed(gf_index* idx, const uint8_t* gene_reversed, int3
  * :118-123 has passed on the device.) */
 int gf_pair_hits_finish(const gf_index* idx, const gf_pair_hit* hits, int64_t n, const char* hit_bases,
                         int64_t hit_bytes, gf_readmatch* out, int32_t* out_status, int32_t n_threads);
+/* The same tail on the DEVICE, for the records while they are still in HBM (d_hits / d_hit_bases / d_totals as
+ * gf_scan_pairs_device wrote them: d_totals[0] = records, at most hits_cap of which exist): a wavefront per record and
+ * side of the break, Levenshtein distance by the block-based bit-vector recurrence of edit_distance.rs:12-92 with the
+ * match masks taken by wave ballots.  d_out: gf_readmatch[hits_cap], d_status: int32[hits_cap] (GF_RM_MATCH, or
+ * GF_ERR_ARG for a record whose contigs or segments are out of range).  Queued on `stream`, nothing synchronised. */
+int gf_pair_hits_finish_device(const gf_index* idx, const void* d_hits, const void* d_totals, int64_t hits_cap,
+                               const void* d_hit_bases, void* d_out, void* d_status, void* stream);
 int64_t gf_scan_pairs_retry_capacity(int64_t n);
 int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
                          int64_t l_bytes, const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets,

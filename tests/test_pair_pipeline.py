@@ -308,3 +308,133 @@ def test_scan_pairs_with_250_base_reads(gpu_device, oracle):
         assert (m.m_read_break, m.m_gap, m.m_left_distance, m.m_right_distance) == (
             rm["read_break"], rm["gap"], rm["left_distance"], rm["right_distance"])
     ix.close()
+
+
+@pytest.mark.gpu
+def test_tail_on_the_device_equals_the_host_tail(gpu_device, oracle):
+    """gf_pair_hits_finish_device (a wavefront per record and side, bit-vector Levenshtein with ballots) against
+    gf_pair_hits_finish (host) and the oracle's calc_distance, on crafted records: both strands, sides that cross a
+    strand (-1) or leave the gene (-2), lengths around the 64-symbol block edges and beyond ten blocks, reads with N and
+    lower case, substitutions and indels against the gene."""
+    import torch
+    from genefuserust_amd import Indexer, _lib
+    from genefuserust_amd.read_pair import PairScan, finish_pair_hits_device
+    from tests.helpers import rand_seq, rc
+    rng = np.random.default_rng(77)
+    genes = [rand_seq(rng, 9000), rand_seq(rng, 7000), rand_seq(rng, 3000)]
+    g1 = bytearray(genes[1]); g1[2000] = ord("N"); genes[1] = bytes(g1)
+    ix = Indexer.from_gene_slices(genes, [False, True, False])
+    ix.make_index()
+    recs, blob = [], bytearray()
+
+    def mutate(s: bytes) -> bytes:
+        s = bytearray(s)
+        for _ in range(int(rng.integers(0, 4))):
+            k = int(rng.integers(0, max(len(s), 1)))
+            op = int(rng.integers(0, 3))
+            if op == 0 and s:
+                s[k] = b"ACGTNa"[int(rng.integers(0, 6))]
+            elif op == 1 and len(s) > 2:
+                del s[k]
+            else:
+                s.insert(k, b"ACGT"[int(rng.integers(0, 4))])
+        return bytes(s)
+
+    lens = [2, 40, 63, 64, 65, 127, 128, 129, 150, 270, 639, 640, 641, 700, 1300]
+    for t in range(260):
+        la, lb = int(rng.choice(lens)), int(rng.choice(lens))
+        ca, cb = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        pa = int(rng.integers(la + 5, len(genes[ca]) - la - 5))
+        pb = int(rng.integers(lb + 5, len(genes[cb]) - lb - 5))
+        left = genes[ca][pa - la + 1:pa + 1]
+        right = genes[cb][pb:pb + lb]
+        sa, sb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        # a read = left part | right part; a part on the reverse strand carries a negative start position
+        lpart = mutate(rc(left) if sa else left)
+        rpart = mutate(rc(right) if sb else right)
+        read = lpart + rpart
+        ll = len(lpart)
+        lpos = -(pa) if sa else pa - ll + 1           # start_gp of the left segment (read base 0)
+        rpos = -(pb + lb - 1) - ll if sb else pb - ll   # start_gp of the right segment, also counted from read base 0
+        if t % 17 == 0:
+            lpos = 3 - ll                               # crosses position 0: -1
+        if t % 19 == 0:
+            rpos = len(genes[cb]) + 50                  # beyond the gene: -2
+        m0 = (0, ll - 1, lpos, ca)
+        m1 = (ll, len(read) - 1, rpos, cb)
+        if t % 2:
+            m0, m1 = m1, m0                             # TOP / SECOND in either order
+        recs.append((t, 1, 0, len(read), 0, len(blob), m0, m1))
+        blob += read
+    n = len(recs)
+    rec = np.zeros(n, dtype=_lib.PAIR_HIT_DTYPE)
+    for k, (pid, src, fl, ln, md, off, m0, m1) in enumerate(recs):
+        rec[k]["pair_id"], rec[k]["source"], rec[k]["flags"], rec[k]["read_len"] = pid, src, fl, ln
+        rec[k]["merge_diff"], rec[k]["seq_offset"] = md, off
+        for j, m in enumerate((m0, m1)):
+            rec[k]["m"][j]["seq_start"], rec[k]["m"][j]["seq_end"], rec[k]["m"][j]["position"], rec[k]["m"][j]["contig"] = m
+    hb = bytes(blob)
+    want = np.zeros(n, dtype=_lib.READMATCH_DTYPE)
+    st = np.zeros(n, dtype=np.int32)
+    _lib.check(_lib.lib().gf_pair_hits_finish(ix._handle(), rec.ctypes.data, n, hb, len(hb), want.ctypes.data, st.ctypes.data, 4))
+    assert (st == _lib.GF_RM_MATCH).all()
+    assert (want["left_distance"] == -1).sum() + (want["right_distance"] == -1).sum() > 5
+    assert (want["left_distance"] == -2).sum() + (want["right_distance"] == -2).sum() > 5
+    assert (want["left_distance"] > 0).sum() > 50 and (want["left_distance"] == 0).sum() > 10
+    dev = torch.device("cuda", gpu_device)
+    cap = n + 7
+    d_hits = torch.zeros((cap, 64), dtype=torch.uint8, device=dev)
+    d_hits[:n] = torch.from_numpy(rec.view(np.uint8).reshape(n, 64)).to(dev)
+    totals = torch.zeros(8, dtype=torch.int64, device=dev)
+    totals[0] = n
+    d_b = torch.from_numpy(np.frombuffer(hb, dtype=np.uint8).copy()).to(dev)
+    out, status = finish_pair_hits_device(ix, PairScan(d_hits, d_b, d_b, totals))
+    got = out[:n].cpu().numpy().view(_lib.READMATCH_DTYPE).reshape(-1)
+    assert (status[:n].cpu().numpy() == _lib.GF_RM_MATCH).all() and (status[n:].cpu().numpy() == 0).all()
+    for f in _lib.READMATCH_DTYPE.names:
+        bad = np.nonzero(got[f] != want[f])[0]
+        assert bad.size == 0, (f, bad[:5], got[f][bad[:5]], want[f][bad[:5]], [recs[i][3] for i in bad[:5]])
+    # the oracle's own distances on a sample (calc_distance through orc_fusion_map_read needs the direction gate: use
+    # plain edit distances of the forward-strand parts instead)
+    for k in range(0, n, 9):
+        h, w = rec[k], want[k]
+        if w["left_distance"] >= 0 and w["left_position"] - (w["read_break"] + 1) + 1 >= 0:
+            seq = hb[int(h["seq_offset"]):int(h["seq_offset"]) + int(w["read_break"]) + 1]
+            g = genes[int(w["left_contig"])].upper()
+            s0 = int(w["left_position"]) - len(seq) + 1
+            assert oracle.edit_distance(seq, g[s0:s0 + len(seq)]) == int(w["left_distance"])
+    # a record that names a gene the index does not have: flagged, the others untouched
+    rec2 = rec[:3].copy()
+    rec2[1]["m"][0]["contig"] = 9
+    d_hits[:3] = torch.from_numpy(rec2.view(np.uint8).reshape(3, 64)).to(dev)
+    totals[0] = 3
+    out, status = finish_pair_hits_device(ix, PairScan(d_hits, d_b, d_b, totals))
+    s3 = status[:3].cpu().numpy()
+    assert s3[0] == _lib.GF_RM_MATCH and s3[1] == _lib.GF_ERR_ARG and s3[2] == _lib.GF_RM_MATCH
+    ix.close()
+
+
+@pytest.mark.gpu
+def test_tail_on_the_device_after_a_real_pair_scan(gpu_device):
+    """files-shaped flow: gf_scan_pairs_device then the device tail on its records, against the host tail."""
+    import torch
+    from genefuserust_amd import Indexer, _lib, synth
+    from genefuserust_amd.read_pair import finish_pair_hits_device, scan_pairs_device
+    genes = synth.make_geneset("IDX-T", scale=0.1)
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    synth.MIXES["JUNC"] = (0.1, 0.4, 0.5)
+    pr = synth.make_pairs(genes, 60_000, read_len=150, mix="JUNC", seed=4, device="cuda")
+    scan = scan_pairs_device(ix, pr.l_bases, pr.l_quals, pr.offsets, pr.r_bases, pr.r_quals, pr.offsets, 150,
+                             hits_cap=60_000, bytes_cap=60_000 * 320)
+    out, status = finish_pair_hits_device(ix, scan)
+    rec, hb, hq, tot = scan.download()
+    n = rec.shape[0]
+    assert n > 500 and tot["overflow"] == 0
+    want = np.zeros(n, dtype=_lib.READMATCH_DTYPE)
+    st = np.zeros(n, dtype=np.int32)
+    recc = np.ascontiguousarray(rec)
+    _lib.check(_lib.lib().gf_pair_hits_finish(ix._handle(), recc.ctypes.data, n, hb, len(hb), want.ctypes.data, st.ctypes.data, 4))
+    got = out[:n].cpu().numpy().view(_lib.READMATCH_DTYPE).reshape(-1)
+    assert got.tobytes() == want.tobytes() and (status[:n].cpu().numpy() == st).all()
+    ix.close()

@@ -32,7 +32,7 @@ def main():
     a = ap.parse_args()
     from genefuserust_amd import FusionMapper, Indexer, synth
     from genefuserust_amd.fastq import fastq_cut_device
-    from genefuserust_amd.read_pair import finish_pair_hits, scan_pairs_device
+    from genefuserust_amd.read_pair import finish_pair_hits, finish_pair_hits_device, scan_pairs_device
     dev = torch.device("cuda", 0)
     genes = synth.make_geneset(a.shape)
     ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
@@ -49,6 +49,7 @@ def main():
     assert b1.n_records == b2.n_records == n
     ms_scan, res = timed(lambda: scan_pairs_device(ix, b1.bases, b1.quals, b1.offsets, b2.bases, b2.quals, b2.offsets, L),
                          a.steps, a.warmup)
+    ms_tail_dev, tail_dev = timed(lambda: finish_pair_hits_device(ix, res), a.steps, a.warmup)
     rec, hb, hq, tot = res.download()
     assert tot["overflow"] == 0, tot
     if a.profile_mode:
@@ -63,6 +64,7 @@ def main():
     rm = np.zeros(rec.shape[0], dtype=_lib.READMATCH_DTYPE)
     st = np.zeros(rec.shape[0], dtype=np.int32)
     recc = np.ascontiguousarray(rec)
+    dev_rm = tail_dev[0][: rec.shape[0]].cpu().numpy().view(_lib.READMATCH_DTYPE).reshape(-1)
     c_s = {}
     for threads in (1, 8):
         t0 = time.perf_counter()
@@ -126,7 +128,10 @@ def main():
         "host_tail": {"hits": len(done), "seconds": round(tail_s, 4), "hits_per_s": len(done) / tail_s if tail_s else None,
                       "note": "finish_pair_hits: gf_pair_hits_finish + one Python ReadMatch object per hit",
                       "library_call_seconds": {str(k): round(v, 5) for k, v in c_s.items()},
-                      "library_hits_per_s_8_threads": rec.shape[0] / c_s[8] if c_s[8] else None},
+                      "library_hits_per_s_8_threads": rec.shape[0] / c_s[8] if c_s[8] else None,
+                      "device_tail_ms": round(ms_tail_dev, 4),
+                      "device_tail_hits_per_s": rec.shape[0] / (ms_tail_dev / 1e3) if ms_tail_dev else None,
+                      "device_tail_equals_host": bool(dev_rm.tobytes() == rm.tobytes())},
         "text_bytes": text_bytes, "text_GBps": text_bytes / (total / 1e3) / 1e9,
         "parity": {"checked_pairs": k, "records_expected": len(flat), "mismatches": bad}}))
     return 1 if bad else 0
