@@ -106,6 +106,21 @@ def traffic_entry(shape: str, n: int, L: int):
         return None
 
 
+class _TorchExchange:
+    """HitExchange (torch.distributed collectives) behind RcclHitExchange's start / finish shape: (merged, totals)."""
+
+    def __init__(self, ex):
+        self.ex, self.cap = ex, ex.cap
+
+    def start(self, hits, n_hits):
+        return self.ex.start(hits, n_hits)
+
+    def finish(self, handle):
+        import torch
+        merged, total, overflow = self.ex.finish(handle)
+        return merged, torch.cat([total.reshape(1), overflow.reshape(1).to(total.dtype)])
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` run plainly: start the N ranks as a CHILD torch.distributed.run (this process has not
     initialised the GPU and never will), let rank 0's JSON line through on our stdout, return the child's exit code."""
@@ -254,9 +269,21 @@ def main() -> None:
             _, nh = ix.compact_hits_device(counts, matches, n, read_id_base=read_id_base, cap=n // 16, out=out_sets[0])
             mx = nh.clone()
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            exch = RcclHitExchange(cap=min(max(4096, 2 * int(mx.item())), max(n // 16, 1)), device=dev)
-            exchange_name = ("gf_allgather_hits_device: one ncclAllGather of %d-record blocks through the C ABI, on a side "
-                             "stream, pipelined one step deep" % exch.cap)
+            cap_x = min(max(4096, 2 * int(mx.item())), max(n // 16, 1))
+            try:
+                exch = RcclHitExchange(cap=cap_x, device=dev)
+                # one exchange before anything is timed: a communicator that cannot move data fails here, on every rank
+                exch.finish(exch.start(out_sets[0][0], nh))
+                torch.cuda.synchronize()
+                exchange_name = ("gf_allgather_hits_device: one ncclAllGather of %d-record blocks through the C ABI, on a side "
+                                 "stream, pipelined one step deep" % exch.cap)
+            except Exception as e:  # noqa: BLE001 — never silent: the line names the path that was timed and why
+                print("rank %d: RCCL exchange through the C ABI failed (%s: %s); timing torch.distributed's all-gather instead"
+                      % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+                from genefuserust_amd.dist import HitExchange
+                exch = _TorchExchange(HitExchange(cap=cap_x, device=dev))
+                exchange_name = ("FALLBACK (gf_allgather_hits_device raised %s): HitExchange over torch.distributed, one asynchronous "
+                                 "fixed-capacity all-gather" % type(e).__name__)
 
     def step(ev=None):
         if ev is not None:
@@ -359,7 +386,7 @@ def main() -> None:
     elif isinstance(out, tuple):  # RcclHitExchange: (merged, totals = [records, overflow flag, per-rank counts ..])
         tot = out[1].cpu().tolist()
         if tot[1]:
-            raise SystemExit("hit exchange over capacity: per-rank counts %s, cap %d" % (tot[2:], exch.cap))
+            raise SystemExit("hit exchange over capacity (cap %d): %s" % (exch.cap, tot[2:]))
         n_hits_total = int(tot[0])
     else:
         n_hits_total = int(out.shape[0])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The round's counter measurements at the bench's own sizes (GPU box): configs 1, 2 (200 M reads) and 4, each through
+# The round's counter measurements at the bench's own sizes (GPU box): configs 1, 2, 3 (200 M reads each) and 4, each through
 # tools/profile_gpu.sh (PMC_SETS=traffic) + tools/make_traffic.py; results under gpurun_out/prof_<tag>_cfg*/ and the
 # updated profiles/hbm_traffic.json copied to gpurun_out/.
 set -o pipefail
@@ -11,6 +11,9 @@ echo "cfg1 done"
 PMC_SETS=min BENCH_ARGS="--config 2 --steps 3" bash tools/profile_gpu.sh ${TAG}_cfg2 > gpurun_out/prof_${TAG}_cfg2.log 2>&1 || { tail -5 gpurun_out/prof_${TAG}_cfg2.log; exit 1; }
 python3 tools/make_traffic.py gpurun_out/prof_${TAG}_cfg2 IDX-C_200000000_150 profiles/${TAG}_cfg2_rocprofv3_summary.txt | tail -6
 echo "cfg2 done"
+PMC_SETS=min BENCH_ARGS="--config 3 --steps 3" bash tools/profile_gpu.sh ${TAG}_cfg3 > gpurun_out/prof_${TAG}_cfg3.log 2>&1 || { tail -5 gpurun_out/prof_${TAG}_cfg3.log; exit 1; }
+python3 tools/make_traffic.py gpurun_out/prof_${TAG}_cfg3 IDX-D_200000000_150 profiles/${TAG}_cfg3_rocprofv3_summary.txt | tail -6
+echo "cfg3 done"
 PMC_SETS=min BENCH_ARGS="--config 4 --steps 1 --warmup 1" bash tools/profile_gpu.sh ${TAG}_cfg4 > gpurun_out/prof_${TAG}_cfg4.log 2>&1 || { tail -5 gpurun_out/prof_${TAG}_cfg4.log; exit 1; }
 python3 tools/make_traffic.py gpurun_out/prof_${TAG}_cfg4 config4_50000000x16_150 profiles/${TAG}_cfg4_rocprofv3_summary.txt --per-step 2 | tail -14
 echo "cfg4 done"
