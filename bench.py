@@ -210,6 +210,9 @@ def main() -> None:
 
     def barrier():
         if world > 1:
+            # drain this rank's own streams first: the hit exchange runs on a communicator and a stream of its own, and
+            # two communicators' collectives must not be in flight in different orders on different ranks
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
