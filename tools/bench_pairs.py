@@ -66,12 +66,14 @@ def main():
     recc = np.ascontiguousarray(rec)
     dev_rm = tail_dev[0][: rec.shape[0]].cpu().numpy().view(_lib.READMATCH_DTYPE).reshape(-1)
     c_s = {}
+    tail_equal = None
     for threads in (1, 8):
         t0 = time.perf_counter()
         for _ in range(5):
             _lib.check(_lib.lib().gf_pair_hits_finish(ix._handle(), recc.ctypes.data, rec.shape[0], hb, len(hb), rm.ctypes.data,
                                                       st.ctypes.data, threads))
         c_s[threads] = (time.perf_counter() - t0) / 5
+    tail_equal = bool(dev_rm.tobytes() == rm.tobytes())
     # parity sample: the records of the first pairs against the oracle-driven policy
     from oracle import oracle_py
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -131,7 +133,7 @@ def main():
                       "library_hits_per_s_8_threads": rec.shape[0] / c_s[8] if c_s[8] else None,
                       "device_tail_ms": round(ms_tail_dev, 4),
                       "device_tail_hits_per_s": rec.shape[0] / (ms_tail_dev / 1e3) if ms_tail_dev else None,
-                      "device_tail_equals_host": bool(dev_rm.tobytes() == rm.tobytes())},
+                      "device_tail_equals_host": tail_equal},
         "text_bytes": text_bytes, "text_GBps": text_bytes / (total / 1e3) / 1e9,
         "parity": {"checked_pairs": k, "records_expected": len(flat), "mismatches": bad}}))
     return 1 if bad else 0
