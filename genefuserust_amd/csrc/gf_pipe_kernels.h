@@ -421,6 +421,10 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // of window 16s+1: a clear bit pair proves that neither can vote, which spares the filter
           // pass those windows.
           uint32_t kill[2] = {0, 0};  // windows 0..63 proven unable to vote (seeds sit at windows 0, 16, 32, 48)
+          // ... of which these are IN the table with six sites or more (HIGH): they cannot vote, but for the vote bound
+          // (gf_table.h) they are not "absent" — a HIGH window may well sit between two voters of one diagonal, and
+          // striking it would split their run (r03: found by enumeration, tests/test_vote_bound.py)
+          uint32_t khigh[2] = {0, 0};
           uint32_t K = GF_NONE_LIN;   // candidate diagonal: site code of read base 0
           // Seed 0 first — filter, then its bucket: most reads that have a candidate diagonal get it
           // here, for one filter line into the L1 instead of four (the kernel is bound by those line
@@ -438,7 +442,10 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             const uint32_t val = gf_lookup(T, key[0]);
             const uint32_t ty = val >> GF_TYPE_SHIFT;
             if (ty == GF_TYPE_UNIQUE) K = val & GF_LIN_MASK;
-            else if (ty != GF_TYPE_DUPES) kill[0] |= 1u;
+            else if (ty != GF_TYPE_DUPES) {
+              kill[0] |= 1u;
+              if (ty == GF_TYPE_HIGH) khigh[0] |= 1u;
+            }
           }
           if (K == GF_NONE_LIN && (T.bloom_in_l2 & GF_SEED_FILTER_MASK)) {
             uint32_t fw[4], fb[4];
@@ -468,7 +475,10 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             const uint32_t val = gf_lookup(T, ks);
             const uint32_t ty = val >> GF_TYPE_SHIFT;
             if (ty == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
-            else if (ty != GF_TYPE_DUPES) kill[s >> 1] |= 1u << (16 * (s & 1));  // absent or >= 6 sites: no vote
+            else if (ty != GF_TYPE_DUPES) {  // absent or >= 6 sites: no vote
+              kill[s >> 1] |= 1u << (16 * (s & 1));
+              if (ty == GF_TYPE_HIGH) khigh[s >> 1] |= 1u << (16 * (s & 1));
+            }
           }
           // windows that cannot vote are not "clean" for what follows
           nvalid -= __popc(cwb[0] & kill[0]) + __popc(cwb[1] & kill[1]);
@@ -505,6 +515,8 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             filt_done = true;
 #pragma unroll
             for (int k = 0; k < NT; ++k) pp[k] = cwb[k];
+            pp[0] |= khigh[0];  // (in the table: they stand, as far as the bound's runs are concerned)
+            pp[1] |= khigh[1];
             bool alive = true;
 #pragma unroll 1
             for (uint32_t rnd = 0; rnd < 2; ++rnd) {
@@ -670,6 +682,10 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             e_v1v2 = (uint32_t)v1;  // v2 = 0: one candidate diagonal per read
 #pragma unroll
             for (int k = 0; k < NT; ++k) e_todo[k] = cwb[k] & ~vmb[k];
+            if (v1 == 0) {  // goes by the bound in gf_k_probe_filter: HIGH seeds stand there too
+              e_todo[0] |= khigh[0];
+              e_todo[1] |= khigh[1];
+            }
           }
         }
       }

@@ -194,3 +194,37 @@ def test_statement_holds_on_strand_junctions_and_tiny_genes(oracle, shim):
         b = rc(b) if rng.random() < 0.5 else b
         reads.append((a[-75:] + b[:75]))
     assert _check_reads(oracle, shim, ox, reads) > 1000
+
+
+def test_high_keys_stand_for_the_bound(oracle, shim):
+    """A window whose key has six sites or more (HIGH) cannot vote, but it IS in the table: it may sit between two
+    voters of one diagonal.  Striking it from the standing windows — as "cannot vote" suggests — splits their run and
+    makes the bound too small: here a read with count1 = 20 and count2 = 10 (it passes the gate of indexer.rs:353-360)
+    would get 19.  gf_k_seedverify_stream therefore keeps HIGH seeds standing (khigh).  Found by enumeration, r03."""
+    rng = np.random.default_rng(314)
+    H = rand_seq(rng, 16)                       # the 16-mer that will be HIGH
+    dump = b"".join(H + rand_seq(rng, 40) for _ in range(7))   # seven copies elsewhere
+    ga = bytearray(rand_seq(rng, 400))
+    gb = bytearray(rand_seq(rng, 400))
+    # read layout (stride-2 windows): run A = windows 2..22 with the HIGH key at window 16, run B = windows 43..53 with
+    # it at window 48; everything else random
+    pa, pb = 100, 150
+    ga[pa + 2 * (16 - 2):pa + 2 * (16 - 2) + 16] = H          # read base 32 = gene A base pa + 28
+    gb[pb + 2 * (48 - 43):pb + 2 * (48 - 43) + 16] = H        # read base 96 = gene B base pb + 10
+    genes = [bytes(ga), bytes(gb), dump]
+    ox = oracle.OracleIndexer(genes)
+    n_h, _ = ox.lookup(oracle.make_kmer(H, 0))
+    assert n_h == -2                                           # HIGH
+    read = bytearray(rand_seq(rng, 150))
+    read[4:4 + (2 * (22 - 2) + 16)] = genes[0][pa:pa + 2 * 20 + 16]      # windows 2..22: bases 4..59
+    read[86:86 + (2 * (53 - 43) + 16)] = genes[1][pb:pb + 2 * 10 + 16]   # windows 43..53: bases 86..121
+    read = bytes(read)
+    present, voters = _votes_and_presence(oracle, ox, read)
+    counts = sorted((len(set(v)) for v in voters.values()), reverse=True)
+    assert counts[0] == 20 and counts[1] == 10                 # passes the first gate: 2*20 >= 40, 2*10 >= 20
+    assert present[16] == 1 and present[48] == 1              # the HIGH windows are in the table
+    assert device_bound(shim, present, 34) >= 20               # the bound over what is in the table holds
+    struck = list(present)
+    struck[16] = struck[48] = 0                                # "cannot vote" mistaken for "absent"
+    assert window_dp(struck) == 19                             # ... would have proved a read dead that passes the gate
+    assert ox.map_read(read) == []                             # (the mismatch gate ends it later: too much of it is random)

@@ -25,7 +25,10 @@ def main():
         rng = np.random.default_rng(seed0 * 1000 + rd)
         shape = ["IDX-T", "IDX-D", "IDX-C"][rd % 3]
         scale = float(rng.choice([0.002, 0.005, 0.02])) * (0.3 if shape == "IDX-C" else 1.0)
-        genes = synth.make_geneset(shape, scale=scale, seed=1000 + rd)
+        # GF_FUZZ_REPEAT: fraction of every gene overwritten by repeat-family copies (default 0.02; 0.3 makes HIGH and
+        # 2..5-fold seeds common: the vote bound's treatment of in-table windows that cannot vote)
+        rep = float(os.environ.get("GF_FUZZ_REPEAT", "0.02"))
+        genes = synth.make_geneset(shape, scale=scale, seed=1000 + rd, repeat_frac=rep)
         ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
         ix.make_index()
         ix.set_map_variant(0)
