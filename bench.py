@@ -273,6 +273,7 @@ def main() -> None:
             mx = nh.clone()
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             cap_x = min(max(4096, 2 * int(mx.item())), max(n // 16, 1))
+            err = None
             try:
                 exch = RcclHitExchange(cap=cap_x, device=dev)
                 # one exchange before anything is timed: a communicator that cannot move data fails here, on every rank
@@ -281,12 +282,17 @@ def main() -> None:
                 exchange_name = ("gf_allgather_hits_device: one ncclAllGather of %d-record blocks through the C ABI, on a side "
                                  "stream, pipelined one step deep" % exch.cap)
             except Exception as e:  # noqa: BLE001 — never silent: the line names the path that was timed and why
-                print("rank %d: RCCL exchange through the C ABI failed (%s: %s); timing torch.distributed's all-gather instead"
-                      % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+                err = e
+                print("rank %d: RCCL exchange through the C ABI failed (%s: %s)" % (rank, type(e).__name__, e),
+                      file=sys.stderr, flush=True)
+            # the ranks agree: one rank on another path would leave the others waiting in a collective nobody joins
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
                 from genefuserust_amd.dist import HitExchange
                 exch = _TorchExchange(HitExchange(cap=cap_x, device=dev))
-                exchange_name = ("FALLBACK (gf_allgather_hits_device raised %s): HitExchange over torch.distributed, one asynchronous "
-                                 "fixed-capacity all-gather" % type(e).__name__)
+                exchange_name = ("FALLBACK (gf_allgather_hits_device failed on a rank%s): HitExchange over torch.distributed, one "
+                                 "asynchronous fixed-capacity all-gather" % ("" if err is None else ": " + type(err).__name__))
 
     def step(ev=None):
         if ev is not None:
