@@ -121,6 +121,8 @@ def lib() -> C.CDLL:
     L.gf_map_reads_hits.restype = C.c_int
     L.gf_map_reads_device.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
     L.gf_map_reads_device.restype = C.c_int
+    L.gf_map_reads_fixed_device.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.gf_map_reads_fixed_device.restype = C.c_int
     L.gf_packed_chunks.argtypes = [i64]
     L.gf_packed_chunks.restype = i64
     L.gf_pack_bases_device.argtypes = [vp, vp, i64, vp, vp, vp]

@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
   uint32_t* s_iv = s_iv_all[wave];
   const int64_t r_lo = (int64_t)blockIdx.x * per_block;
   const int64_t r_hi = r_lo + per_block < n ? r_lo + per_block : n;
+  const int64_t fixed_len = T.fixed_len;
   GfPipeEntryW<PW>* my_list = list_b + r_lo;
   for (int64_t g0 = r_lo + 64 * (int64_t)wave; g0 < r_hi; g0 += 256) {
     const int64_t g1 = g0 + 64 < r_hi ? g0 + 64 : r_hi;
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       // the reads r0 .. r0+nfit-1 (a prefix of the group) fit in the tile.  The tile starts at
       // the 16-byte boundary at or below the first read (pointer arithmetic on `bases` keeps
       // the loads in the global address space with a scalar base).
-      const int64_t base_off = offsets[r0];
+#define GF_OFF(x) (fixed_len ? (int64_t)(x) * fixed_len : offsets[x])  // (fixed_len is wave-uniform: a scalar branch)
+      const int64_t base_off = GF_OFF(r0);
       const uint8_t* p0 = bases + base_off;
       const uint32_t mis = PACKED ? (uint32_t)(base_off & 15) : (uint32_t)((uintptr_t)p0 & 15u);
       const uint4* src = (const uint4*)(p0 - mis);
@@ -279,15 +281,15 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       const int64_t r = r0 + lane;
       int64_t off0 = 0, off1 = 0;
       if (r < g1) {
-        off0 = offsets[r];
-        off1 = offsets[r + 1];
+        off0 = GF_OFF(r);
+        off1 = GF_OFF(r + 1);
       }
       const bool fits = r < g1 && (uint64_t)(off1 - base_off) + mis <= (uint64_t)TILE_BYTES;
       int nfit = __popcll(__ballot(fits));
       const bool oversize = nfit == 0;  // a single read larger than the tile: far beyond lmax, nothing to stage
       if (oversize) nfit = 1;
       gf_wave_lds_sync();  // the previous tile's LDS reads are done
-      const uint32_t chunks = oversize ? 0u : (uint32_t)((offsets[r0 + nfit] - base_off) + mis + 15) >> 4;
+      const uint32_t chunks = oversize ? 0u : (uint32_t)((GF_OFF(r0 + nfit) - base_off) + mis + 15) >> 4;
       if (PACKED && chunks > 0) {
         uint32_t qp[NLOAD], qi[NLOAD];
 #pragma unroll
@@ -1078,8 +1080,8 @@ __global__ __launch_bounds__(WAVES * 64, LCAP <= 256 ? 8 : (LCAP <= 1024 ? 3 : 1
   const unsigned int nl = *n_list;
   for (unsigned int k = blockIdx.x * WAVES + wib; k < nl; k += gridDim.x * WAVES) {
     const int64_t r = (int64_t)list[(int64_t)k * stride];
-    const int64_t off0 = offsets[r];
-    const int L = (int)(offsets[r + 1] - off0);
+    const int64_t off0 = T.fixed_len ? r * (int64_t)T.fixed_len : offsets[r];
+    const int L = T.fixed_len ? T.fixed_len : (int)(offsets[r + 1] - off0);
     gf_wave_lds_sync();
     uint32_t sh;
     if constexpr (PACKED) sh = gf_stage_read_packed<LCAP>(S, g_pk, g_iv, off0, L, lane);

@@ -88,6 +88,10 @@ struct GfTable {
   // pipeline maps R1 / R2 in place and skips the pairs whose merged read is searched instead
   // (pescanner.rs:446-471): skip = the merged lengths.
   const int32_t* skip;
+  // per-call, optional: > 0 = every read has exactly this many bases and read r starts at base r * fixed_len: the
+  // kernels compute the offsets instead of loading them (gf_map_reads_fixed_device; r03: the int64 offsets are 2.5 M of
+  // seed+verify's 75.6 M missed lines per 20 M reads: -2.3 % of its time)
+  int32_t fixed_len;
 };
 
 // filter word and bit pair of a 14-mer x (28 bits).  One multiplicative hash: the word comes

@@ -838,13 +838,16 @@ static int segment_mask_test_impl(const gf_index* idx, const uint8_t* masks, con
 
 static int map_span_device(const gf_index* idx, const ReadSrc& src, const int64_t* offsets, int64_t n,
                            int32_t max_read_len, uint8_t* counts, gf_seqmatch* matches, hipStream_t st, bool prof,
-                           const int32_t* skip) {
+                           const int32_t* skip, int32_t fixed_len = 0) {
   gf_index* mix = const_cast<gf_index*>(idx);
   const uint8_t* bases = src.bases;
   if (src.packed() && idx->map_variant != 0)
     return fail(GF_ERR_ARG, "packed reads are taken by the flat pipeline only (gf_set_map_variant 0)");
   GfTable T = idx->table;
   T.skip = skip;  // (per call: the index itself stays read-only)
+  T.fixed_len = fixed_len;
+  if (fixed_len > 0 && (idx->map_variant != 0 || fixed_len > 320))
+    return fail(GF_ERR_ARG, "fixed-length batches are taken by the flat pipeline only (reads of up to 320 bases, gf_set_map_variant 0)");
   // persistent grid: enough waves to fill every CU, reads interleaved across waves
   // One launch per read-length class present in the batch (<=256, <=1024, <=4096);
   // each launch skips the reads of the other classes, so short reads always get the
@@ -917,10 +920,11 @@ static int64_t span_max_reads() {
 
 static int map_reads_device_impl(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
                                  int32_t max_read_len, void* d_counts, void* d_matches, void* stream,
-                                 const int32_t* d_skip, const void* d_pk = nullptr, const void* d_iv = nullptr) {
+                                 const int32_t* d_skip, const void* d_pk = nullptr, const void* d_iv = nullptr,
+                                 int32_t fixed_len = 0) {
   if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
   if (n == 0) return GF_OK;
-  if (!d_offsets || !d_counts || !d_matches) return fail(GF_ERR_ARG, "null device pointer");
+  if ((!d_offsets && fixed_len <= 0) || !d_counts || !d_matches) return fail(GF_ERR_ARG, "null device pointer");
   if (max_read_len > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "max_read_len exceeds GF_MAX_READ_LEN");
   DeviceGuard guard(idx->device);
   hipStream_t st = (hipStream_t)stream;
@@ -947,8 +951,13 @@ static int map_reads_device_impl(const gf_index* idx, const void* d_bases, const
   for (int64_t s0 = 0; s0 < n; s0 += span) {
     const int64_t ns = std::min(span, n - s0);
     // offsets are absolute positions in `bases`: a span is the same call on a later part of the arrays
-    const int rc = map_span_device(idx, src, offsets + s0, ns, max_read_len, counts + s0, matches + 2 * s0, st, prof,
-                                   d_skip ? d_skip + s0 : nullptr);
+    ReadSrc span_src = src;
+    if (fixed_len > 0) {  // a span of a fixed-length batch is the same call on later bases: read indices restart at 0
+      if (span_src.bases) span_src.bases += s0 * (int64_t)fixed_len;
+      if (span_src.packed() && ((s0 * (int64_t)fixed_len) & 15)) return fail(GF_ERR_ARG, "packed fixed-length batch beyond one span");
+    }
+    const int rc = map_span_device(idx, span_src, fixed_len > 0 ? nullptr : offsets + s0, ns, max_read_len, counts + s0,
+                                   matches + 2 * s0, st, prof, d_skip ? d_skip + s0 : nullptr, fixed_len);
     if (rc != GF_OK) return rc;
   }
   if (prof) {
@@ -1015,6 +1024,14 @@ int gf_map_reads_packed_device(const gf_index* idx, const void* d_pk, const void
 int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
                         int32_t max_read_len, void* d_counts, void* d_matches, void* stream) {
   return map_reads_device_impl(idx, d_bases, d_offsets, n, max_read_len, d_counts, d_matches, stream, nullptr);
+}
+
+int gf_map_reads_fixed_device(const gf_index* idx, const void* d_bases, int64_t n, int32_t read_len, void* d_counts,
+                              void* d_matches, void* stream) {
+  if (read_len < 1 || read_len > 320) return fail(GF_ERR_ARG, "read_len must be 1..320 for a fixed-length batch");
+  if (n > 0 && !d_bases) return fail(GF_ERR_ARG, "null device pointer");
+  return map_reads_device_impl(idx, d_bases, nullptr, n, read_len, d_counts, d_matches, stream, nullptr, nullptr, nullptr,
+                               read_len);
 }
 
 int64_t gf_compact_workspace_bytes(int64_t n) {

@@ -383,6 +383,20 @@ class Indexer:
                                                   int(max_read_len), counts.data_ptr(), matches.data_ptr(), st))
         return counts, matches
 
+    def map_reads_fixed_device(self, bases, read_len: int, counts=None, matches=None, stream=None):
+        """A batch of reads of one length laid back to back (gf_map_reads_fixed_device): no offsets array."""
+        import torch
+        assert bases.dtype == torch.uint8 and bases.is_cuda and bases.numel() % int(read_len) == 0
+        n = bases.numel() // int(read_len)
+        if counts is None:
+            counts = torch.empty(max(n, 1), dtype=torch.uint8, device=bases.device)
+        if matches is None:
+            matches = torch.empty((max(n, 1), 2, 4), dtype=torch.int32, device=bases.device)
+        st = torch.cuda.current_stream(bases.device).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().gf_map_reads_fixed_device(self._handle(), bases.data_ptr(), n, int(read_len), counts.data_ptr(),
+                                                        matches.data_ptr(), st))
+        return counts, matches
+
     def pack_bases_device(self, bases, stream=None):
         """The 2-bit + bad-bit form of a whole ``bases`` buffer (gf_pack_bases_device): (pk int32, iv int16)
         tensors; reads are then given by the same offsets.  Worth it when the reads are mapped more than once."""

@@ -178,6 +178,12 @@ int gf_map_reads_hits(const gf_index* idx, const char* bases, const int64_t* off
 int gf_map_reads_device(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
                         int32_t max_read_len, void* d_counts, void* d_matches, void* stream);
 
+/* The same for a batch of reads of ONE length laid back to back (read r = bases r * read_len .. (r+1) * read_len - 1;
+ * read_len <= 320): no offsets array — the kernels compute what they would load (8 bytes per read less to move: 2.3 %
+ * of the mapping time at 150 bases).  Results identical to gf_map_reads_device with offsets[r] = r * read_len. */
+int gf_map_reads_fixed_device(const gf_index* idx, const void* d_bases, int64_t n, int32_t read_len, void* d_counts,
+                              void* d_matches, void* stream);
+
 /* --- packed hand-over ---------------------------------------------------------------------------
  * The mapping kernels work on 2 bits per base + 1 "not A/C/G/T" bit; with ASCII input they convert
  * while they stage.  A host that maps the same reads more than once (multi-CSV mode: one index per

@@ -574,3 +574,29 @@ def test_packed_hand_over_synthetic_and_rate(gpu_device):
         _dense_equal(a, b, n)
         assert int((a[0] > 0).sum()) > 500
     ix.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [64, 100, 150, 151, 160, 161, 250, 320])
+def test_fixed_length_batches_equal_the_offsets_form(gpu_device, L):
+    """gf_map_reads_fixed_device (offsets computed, not loaded) == gf_map_reads_device with offsets[r] = r * L, for every
+    word class of the flat pipeline, batch sizes that are no multiple of a wavefront, N and lower case in the reads."""
+    import torch
+    from genefuserust_amd import Indexer, synth
+    genes = synth.make_geneset("IDX-T", scale=0.05)
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    synth.MIXES["TEST"] = (0.3, 0.4, 0.3)
+    n = 70_001
+    rb = synth.make_reads(genes, n, read_len=L, mix="TEST", seed=100 + L, device="cuda")
+    bases = rb.bases.clone()
+    bases[torch.randint(0, bases.numel(), (200,), device="cuda")] = ord("n")
+    c0, m0 = ix.map_reads_device(bases, rb.offsets, L)
+    c1, m1 = ix.map_reads_fixed_device(bases, L)
+    assert L < 100 or int((c0 > 0).sum()) > 1000   # (a 54-base read has 20 windows: nothing passes the gate)
+    assert torch.equal(c0, c1)
+    nz = (c0 > 0).nonzero().flatten()
+    assert torch.equal(m0[nz, 0], m1[nz, 0])
+    two = (c0 == 2).nonzero().flatten()
+    assert torch.equal(m0[two, 1], m1[two, 1])
+    ix.close()
