@@ -18,6 +18,9 @@
  * are independent, on one stream they run in call order.  Profiling (gf_set_profiling) and
  * gf_set_map_variant are single-threaded switches for experiments.
  *
+ * Linking: libgfmatch.so needs libamdhip64 and librccl (the one exchange between GPUs, gf_comm_* below, calls RCCL
+ * itself); a process that has loaded another copy of either under the same SONAME (PyTorch-ROCm bundles both) shares it.
+ *
  * Device buffers: the kernels load whole aligned 16-byte chunks around a batch's span of bases —
  * up to 15 bytes before d_bases + offsets[0] and up to 15 (FASTQ/merge: 63) past the last base are
  * READ (never written, never interpreted).  Inside any whole allocation that is always
