@@ -226,6 +226,12 @@ __device__ __forceinline__ uint32_t gf_window_mask(int nwin, int k) {
 #ifndef GF_SEED_FILTER_MASK
 #define GF_SEED_FILTER_MASK 2u
 #endif
+#ifndef GF_MID_SEEDS
+#define GF_MID_SEEDS 2  // seeds probed by seed+verify when the filter is not L2-resident (4 = all, as before r03)
+// (r03, IDX-C, ms per 20 M reads: PANEL 3.78 with four seeds, 3.50 with two, 3.68 with one; all-background 6.18 / 5.54 /
+//  5.27 — a background read pays a missed line per seed, an on-target read whose seeds name nothing pays the filter
+//  sweeps and two or three probes in gf_k_probe_buckets)
+#endif
 #ifndef GF_FILTER_AUX
 #define GF_FILTER_AUX 0  // cache policy bits of the inline filter's buffer loads (experiments: 1 sc0, 2 nt, 16 sc1)
 #endif
@@ -468,6 +474,10 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           if (okm == 0x1234567u) counts[r] = 1;
           okm = 0;
 #endif
+          // With a filter that lives beyond the L2 the seeds go to their buckets unasked, and then only GF_MID_SEEDS of
+          // them (r03): a background read's four misses were a quarter of IDX-C's seed+verify; a read whose first
+          // seeds name nothing gets its diagonal in gf_k_probe_buckets, if it outlives the filter sweeps.
+          if (T.bloom_in_l2 != 2) okm &= (1u << GF_MID_SEEDS) - 1u;
           // one bucket probe at a time, in seed order, until one names a diagonal: an
           // on-target read costs one L2-missing request here
           while (okm != 0 && K == GF_NONE_LIN) {  // (a wave runs as many rounds as its unluckiest lane needs)
@@ -985,6 +995,39 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
   if (threadIdx.x == 0) blk_cnt2[blockIdx.x] = s_cnt;
 }
 
+// pass B of seed+verify on an entry's words (registers, the read starts at bit 0 of pk[0]): the windows whose 16 bases
+// equal the bases of site K + 2w and whose site is the only one of its key, one bit per stride-2 window.  No
+// "bad base" stream here: the caller intersects the result with windows known to be clean.
+template <int PW>
+__device__ __forceinline__ void gf_verify_words(const GfTable& T, const uint32_t (&pk)[PW + 1], uint32_t K,
+                                                uint32_t (&vmb)[GfPipeEntryW<PW>::NT]) {
+  constexpr int NT = GfPipeEntryW<PW>::NT;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) vmb[k] = 0;
+  const uint2* gp = (const uint2*)T.gdu + (K >> 4);
+  const uint32_t bo = 2u * (K & 15u);
+  uint2 gw[PW + 1];
+#pragma unroll
+  for (int j = 0; j < PW + 1; ++j) gw[j] = gp[j];
+  uint32_t zz_cur;
+  {
+    const uint32_t x = pk[0] ^ __builtin_amdgcn_alignbit(gw[1].x, gw[0].x, bo);
+    zz_cur = (x | (x >> 1)) & 0x55555555u;
+  }
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    uint32_t zz_next = 0x55555555u;
+    if (j + 1 < PW) {
+      const uint32_t x = pk[j + 1] ^ __builtin_amdgcn_alignbit(gw[j + 2 <= PW ? j + 2 : PW].x, gw[j + 1].x, bo);
+      zz_next = (x | (x >> 1)) & 0x55555555u;
+    }
+    const uint32_t u = __builtin_amdgcn_alignbit(gw[j + 1].y, gw[j].y, bo);
+    const uint32_t ver = gf_clean16(zz_cur, zz_next) & u & 0x11111111u;
+    vmb[j >> 2] |= gf_gather_nibble_lsb(ver) << (8 * (j & 3));
+    zz_cur = zz_next;
+  }
+}
+
 template <int PW>
 __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPipeEntryW<PW>* __restrict__ list_b,
                                                           const unsigned int* __restrict__ blk_cnt2,
@@ -1006,13 +1049,22 @@ __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPip
       constexpr int NT = GfPipeEntryW<PW>::NT;
       uint32_t v1v2, p[NT], pk[PW + 1];
       gf_entry_load<PW>(my_list + t, r, v1v2, p, pk);
-      const int v1 = (int)(v1v2 & 0xFFu), v2 = (int)((v1v2 >> 8) & 0xFFu);
+      int v1 = (int)(v1v2 & 0xFFu);
+      const int v2 = (int)((v1v2 >> 8) & 0xFFu);
 #pragma unroll
       for (int j = 0; j <= PW; ++j) s_pk[j * 256 + threadIdx.x] = pk[j];  // the loop indexes the words dynamically
       int left = 0;
 #pragma unroll
       for (int k = 0; k < NT; ++k) left += __popc(p[k]);
       int h = 0;
+      // A read that comes without a candidate diagonal (seed+verify found none: it asks only its first seed when the
+      // filter lives beyond the L2, r03) gets one here: the first window whose bucket holds a UNIQUE site names K, the
+      // read is verified against the genes on K like in seed+verify, and the windows that match there — they vote for
+      // K and for nothing else — leave the list: an on-target read costs two or three probes instead of sixty.
+      bool want_k = v1 == 0 && v2 == 0;
+      uint32_t p0[NT], voted[NT];  // the windows standing on entry (all clean); those probed so far that voted
+#pragma unroll
+      for (int k = 0; k < NT; ++k) { p0[k] = p[k]; voted[k] = 0; }
       bool dead = (v1 + left < GF_MAJOR_KEYS / 2) || (v2 + left < GF_MINOR_KEYS / 2);
       while (!dead && left > 0) {
         // the read dies only after at least `need` more probes miss: issue that many (up to
@@ -1023,6 +1075,7 @@ __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPip
         need = need < 1 ? 1 : (need > 4 ? 4 : need);
         uint32_t key[4];
         bool act[4];
+        int wv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           uint32_t any = 0;
@@ -1041,20 +1094,45 @@ __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPip
               }
             }
           }
+          wv[u] = w;
           const int j = w >> 3;
           const uint32_t sh = 4u * (uint32_t)(w & 7);
           key[u] = __builtin_amdgcn_alignbit(s_pk[(j + 1) * 256 + threadIdx.x], s_pk[j * 256 + threadIdx.x], sh);
         }
-        uint32_t ty[4] = {0, 0, 0, 0};
+        uint32_t val[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (act[u]) ty[u] = gf_lookup<GF_PROBE_NT>(T, key[u]) >> GF_TYPE_SHIFT;
+          if (act[u]) val[u] = gf_lookup<GF_PROBE_NT>(T, key[u]);
+        uint32_t K = GF_NONE_LIN;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (act[u]) {
-            h += (ty[u] == GF_TYPE_UNIQUE || ty[u] == GF_TYPE_DUPES) ? 1 : 0;
+            const uint32_t ty = val[u] >> GF_TYPE_SHIFT;
+            if (ty == GF_TYPE_UNIQUE || ty == GF_TYPE_DUPES) {
+              h += 1;
+              voted[wv[u] >> 5] |= 1u << (wv[u] & 31);
+              if (want_k && ty == GF_TYPE_UNIQUE && K == GF_NONE_LIN) K = (val[u] & GF_LIN_MASK) - 2u * (uint32_t)wv[u];
+            }
             left -= 1;
           }
+        }
+        if (K != GF_NONE_LIN) {
+          want_k = false;
+          uint32_t vk[NT];
+          gf_verify_words<PW>(T, pk, K, vk);
+          int nv = 0, nh = 0;
+#pragma unroll
+          for (int k = 0; k < NT; ++k) {
+            vk[k] &= p0[k];                 // clean windows only (the words past the read's end compared garbage)
+            nv += __popc(vk[k]);
+            nh += __popc(vk[k] & voted[k]);  // probed already and counted in h: they are v1's now
+            p[k] &= ~vk[k];
+          }
+          v1 = nv;
+          h -= nh;
+          left = 0;
+#pragma unroll
+          for (int k = 0; k < NT; ++k) left += __popc(p[k]);
         }
         dead = (v1 + h + left < GF_MAJOR_KEYS / 2) || (v2 + h + left < GF_MINOR_KEYS / 2);
       }
