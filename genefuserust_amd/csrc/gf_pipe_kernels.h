@@ -896,13 +896,17 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
             dead = bound() < GF_MAJOR_KEYS / 2;
           }
           v1v2 |= GF_ENTRY_FILTERED;
-        } else {             // part by part: every pair of this part; the bound once every part has been asked
+        } else if (!last_part) {  // part by part: every pair of this part; nothing can be decided yet
           ask(0u);
           ask(1u);
-          if (last_part) {
+        } else {                  // the last part: its even pairs may already settle it (pairs not asked stand)
+          ask(0u);
+          dead = bound() < GF_MAJOR_KEYS / 2;
+          if (!dead) {
+            ask(1u);
             dead = bound() < GF_MAJOR_KEYS / 2;
-            v1v2 |= GF_ENTRY_FILTERED;
           }
+          v1v2 |= GF_ENTRY_FILTERED;
         }
 #pragma unroll
         for (int k = 0; k < NT; ++k) pp[k] = m[k];
