@@ -59,6 +59,32 @@ __global__ __launch_bounds__(256) void gf_k_upper_inplace(uint8_t* __restrict__ 
   }
 }
 
+// The same out of place, `src` being the host's pinned staging block: the kernel pulls a chunk of the gene bytes
+// over the bus itself as soon as the host has gathered it (r03: a DMA per megabyte cost 40 us of set-up each, a
+// launch of this costs 5).
+__global__ __launch_bounds__(256) void gf_k_upper_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                       unsigned long long n_vec) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t* v = (const u32x4_t*)src;
+  uint4* o = (uint4*)dst;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (unsigned long long)gridDim.x * 256) {
+    const u32x4_t q = __builtin_nontemporal_load(v + i);
+    uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t x = w[k], y = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        uint32_t ch = (x >> (8 * b)) & 0xFFu;
+        if (ch - 'a' < 26u) ch -= 32u;
+        y |= ch << (8 * b);
+      }
+      w[k] = y;
+    }
+    o[i] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 __device__ __forceinline__ uint64_t gf_atomic_load64(uint64_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -450,8 +476,167 @@ __global__ void gf_k_index_side(const GfSideEntry* __restrict__ side, unsigned l
     const uint32_t val = *(const uint32_t*)s;
     if (((val & GF_VAL_LOW) >> GF_TYPE_SHIFT) != GF_TYPE_DUPES) continue;
     const uint32_t cnt = (val >> GF_DUPE_COUNT_SHIFT) & 7u, start = val & GF_DUPE_START_MASK;
-    for (uint32_t k = 0; k < cnt; ++k)
-      if (atomicCAS(dupes + start + k, GF_DUPE_EMPTY, e.lin) == GF_DUPE_EMPTY) break;
+    for (uint32_t k = 0; k < cnt; ++k) {
+      if (atomicCAS(dupes + start + k, GF_DUPE_EMPTY, e.lin) != GF_DUPE_EMPTY) continue;
+      // A list fills from its front (a thread takes entry k only after it saw 0 .. k-1 taken), so whoever takes
+      // the LAST entry knows the list complete and sorts it here, ascending (reproducible content) — the sweep
+      // over the whole table that did this (gf_k_sort_dupes) was 0.1 ms of a cancer-sized build.
+      if (k == cnt - 1 && cnt > 1) {
+        uint32_t d[GF_DUP_THRESHOLD];
+#pragma unroll
+        for (uint32_t a = 0; a < GF_DUP_THRESHOLD; ++a)
+          d[a] = a + 1 < cnt ? __hip_atomic_load(dupes + start + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : (a + 1 == cnt ? e.lin : 0xFFFFFFFFu);
+#pragma unroll
+        for (int a = 1; a < (int)GF_DUP_THRESHOLD; ++a)  // (insertion sort of five registers; the unused ones are maximal)
+#pragma unroll
+          for (int b = a; b > 0; --b)
+            if (d[b - 1] > d[b]) { const uint32_t t = d[b]; d[b] = d[b - 1]; d[b - 1] = t; }
+#pragma unroll
+        for (uint32_t a = 0; a < GF_DUP_THRESHOLD; ++a)
+          if (a < cnt) __hip_atomic_store(dupes + start + a, d[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      break;
+    }
+  }
+}
+
+// ---- the presence filter without global atomics (r03) ----
+// Device-scope atomics are carried out beyond the L2s on this chip, about 22 G of them a second whatever they
+// touch (tools/exp_build_costs.hip: 45 ps per CAS into the table, 55 ps per look-then-atomicOr into a 7.7 MiB
+// filter), and gf_k_index_insert is exactly their sum: 30 M CAS + 15 M filter ORs = 2.05 ms on a cancer-sized gene
+// set.  The filter's share goes: the hashes are scattered into partitions of GF_FSLICE_WORDS filter words (the
+// word index is monotone in the hash, so a partition is a hash range), a block per partition ORs its hashes into
+// LDS and writes its 32 KB of filter once.  A partition that outgrows its room (a gene set of one repeated
+// 14-mer) sends the excess through the atomic as before — which the building block ORs over, not overwrites.
+#define GF_FSLICE_WORDS 8192u
+#define GF_FPARTS_MAX 256u
+
+__global__ __launch_bounds__(GF_INDEX_THREADS) void gf_k_filter_scatter(GfGenes G, uint32_t* bloom, uint32_t bloom_words,
+                                                                        uint32_t nparts, uint32_t* part_buf,
+                                                                        uint32_t part_cap, unsigned int* part_fill) {
+  __shared__ uint32_t s_codes[GF_TILE_BASES / 16 + 2];
+  __shared__ uint32_t s_inv[GF_TILE_BASES / 32 + 2];
+  __shared__ uint32_t s_h[2 * GF_TILE_BASES];
+  __shared__ unsigned int s_cnt[GF_FPARTS_MAX], s_base[GF_FPARTS_MAX];
+  __shared__ unsigned int s_n;
+  __shared__ uint32_t s_goff[64];
+  const uint32_t t0 = blockIdx.x * GF_TILE_BASES;
+  const int tid = threadIdx.x;
+  for (int ch = tid; ch < GF_TILE_BASES / 16 + 1; ch += GF_INDEX_THREADS) {
+    uint4 q = *(const uint4*)(G.cat + (size_t)t0 + 16u * ch);
+    uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+    gf_convert4(q.x, c0, i0);
+    gf_convert4(q.y, c1, i1);
+    gf_convert4(q.z, c2, i2);
+    gf_convert4(q.w, c3, i3);
+    s_codes[ch] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+    ((uint16_t*)s_inv)[ch] = (uint16_t)(i0 | (i1 << 4) | (i2 << 8) | (i3 << 12));
+  }
+  if (tid == 0) {
+    s_codes[GF_TILE_BASES / 16 + 1] = 0;
+    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 1] = 0xFFFF;
+    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 2] = 0xFFFF;
+    ((uint16_t*)s_inv)[GF_TILE_BASES / 16 + 3] = 0xFFFF;
+    s_n = 0;
+  }
+  for (int p = tid; p < (int)GF_FPARTS_MAX; p += GF_INDEX_THREADS) s_cnt[p] = 0;
+  // the genes this tile touches, found once (a tile is a fifth of an average gene: one or two of them; a search of
+  // the offsets per base, ten dependent loads, was most of this kernel's time)
+  if (tid < 64) {
+    int lo = 0, hi = G.n_genes;  // invariant gene_off[lo] <= t0 < gene_off[hi]  (t0 < total)
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (G.gene_off[mid] <= t0) lo = mid; else hi = mid;
+    }
+    const int c = lo + tid;
+    s_goff[tid] = c <= G.n_genes ? G.gene_off[c] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  // (a tile of more than 62 genes — slices of a few dozen bases — goes by the search after all)
+  const bool few = s_goff[63] == 0xFFFFFFFFu || s_goff[63] >= t0 + GF_TILE_BASES + GF_KMER;
+  // the tile's hashes, in any order: a window with a key enters its first 14 bases, and its last 14 where
+  // window + 2 has no key of its own (gf_k_index_insert's rule, word for word)
+  for (int l0 = 0; l0 < GF_TILE_BASES; l0 += GF_INDEX_THREADS) {  // (every lane of a wave stays in the loop)
+    const int l = l0 + tid;
+    const uint32_t g = t0 + (uint32_t)l;
+    bool has = false, next_has = false;
+    uint32_t key = 0;
+    if (g < G.total) {
+      const uint32_t sh = (uint32_t)l & 31u;
+      const uint32_t lo_w = s_inv[l >> 5], hi_w = s_inv[(l >> 5) + 1];
+      const uint32_t inv = sh ? ((lo_w >> sh) | (hi_w << (32u - sh))) : lo_w;
+      if ((inv & 0xFFFFu) == 0) {
+        uint32_t f, len;
+        if (few) {
+          int k = 0;
+          while (s_goff[k + 1] <= g) ++k;  // (gene_off[n_genes] = total > g ends it)
+          f = g - s_goff[k];
+          len = s_goff[k + 1] - s_goff[k];
+        } else {
+          int lo = 0, hi = G.n_genes;  // invariant gene_off[lo] <= g < gene_off[hi]
+          while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (G.gene_off[mid] <= g) lo = mid; else hi = mid;
+          }
+          f = g - G.gene_off[lo];
+          len = G.gene_off[lo + 1] - G.gene_off[lo];
+        }
+        if (f + GF_KMER <= len) {
+          key = gf_window(s_codes[l >> 4], s_codes[(l >> 4) + 1], (uint32_t)l);
+          has = f + GF_KMER < len || f >= 1;  // a forward or a reverse site
+          next_has = ((inv >> 2) & 0xFFFFu) == 0 && f + 2 + GF_KMER <= len && l + 2 + GF_KMER <= GF_TILE_BASES + 16;
+        }
+      }
+    }
+    const bool two = has && !next_has;
+    unsigned int at = gf_ix_wave_append_lds(has, &s_n);
+    if (has) s_h[at] = GF_BLOOM_HASH((key & 0x0FFFFFFFu));
+    at = gf_ix_wave_append_lds(two, &s_n);
+    if (two) s_h[at] = GF_BLOOM_HASH((key >> 4));
+  }
+  __syncthreads();
+  const unsigned int n = s_n;
+  for (unsigned int i = tid; i < n; i += GF_INDEX_THREADS)
+    atomicAdd(&s_cnt[GF_BLOOM_WORD(s_h[i], bloom_words) / GF_FSLICE_WORDS], 1u);
+  __syncthreads();
+  for (int p = tid; p < (int)nparts; p += GF_INDEX_THREADS) {
+    const unsigned int c = s_cnt[p];
+    s_base[p] = c ? atomicAdd(part_fill + p, c) : 0u;
+    s_cnt[p] = 0;
+  }
+  __syncthreads();
+  for (unsigned int i = tid; i < n; i += GF_INDEX_THREADS) {
+    const uint32_t h = s_h[i];
+    const uint32_t w = GF_BLOOM_WORD(h, bloom_words), p = w / GF_FSLICE_WORDS;
+    const unsigned int at = s_base[p] + atomicAdd(&s_cnt[p], 1u);
+    if (at < part_cap) {
+      part_buf[(size_t)p * part_cap + at] = h;
+    } else {  // no room: the old way (the builder ORs over it)
+      const uint32_t b = GF_BLOOM_BITS(h);
+      if ((__builtin_nontemporal_load(bloom + w) & b) != b) atomicOr(bloom + w, b);
+    }
+  }
+}
+
+// one block per partition: its hashes into 32 KB of LDS, ORed over what the scatter's overflow left in the filter
+__global__ __launch_bounds__(1024) void gf_k_filter_build(uint32_t* bloom, uint32_t bloom_words,
+                                                          const uint32_t* __restrict__ part_buf, uint32_t part_cap,
+                                                          const unsigned int* __restrict__ part_fill) {
+  __shared__ unsigned int s_w[GF_FSLICE_WORDS];
+  const uint32_t p = blockIdx.x, w0 = p * GF_FSLICE_WORDS;
+  for (uint32_t i = threadIdx.x; i < GF_FSLICE_WORDS; i += 1024) s_w[i] = 0;
+  __syncthreads();
+  const uint32_t n = min(part_fill[p], part_cap);
+  const uint32_t* mine = part_buf + (size_t)p * part_cap;
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+    const uint32_t h = __builtin_nontemporal_load(mine + i);
+    atomicOr(&s_w[GF_BLOOM_WORD(h, bloom_words) - w0], GF_BLOOM_BITS(h));
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < GF_FSLICE_WORDS; i += 1024) {
+    const uint32_t w = w0 + i;
+    if (w < bloom_words && s_w[i]) bloom[w] |= s_w[i];
   }
 }
 
@@ -525,7 +710,8 @@ __global__ __launch_bounds__(256) void gf_k_index_strands(GfGenes G, const uint3
 }
 
 // stats[0]=n_sites [1]=n_keys [2]=n_unique [3]=n_dupe_keys [4]=n_high [5]=n_dupe_sites
-// [6]=dupes cursor
+// [6]=dupes cursor (the extent of dupes[] handed out, granules' unused ends included)
+#define GF_DUPE_GRANULE 512ull
 // One sweep over the table after the COUNT pass: counts -> unique / dupes(start in dupes[]) / HIGH, and the
 // statistics on the way.  A thread takes one bucket (8 consecutive slots = one 64-byte line), a block 256
 // buckets per round: the room in dupes[] for the round's 2..5-fold keys is ONE atomic on the shared counter (a
@@ -533,31 +719,33 @@ __global__ __launch_bounds__(256) void gf_k_index_strands(GfGenes G, const uint3
 // atomics on a cancer-sized table, most of the kernel's 1.16 ms.  The statistics are one atomic per block and
 // number (one per wave serialised ~100 K atomics on six addresses).
 __global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uint64_t nslots, unsigned long long* stats) {
+  // (r03: a lane takes slot PAIRS — one 16-byte load, the wave's loads contiguous — four of them a round; a lane per
+  //  bucket read the table in 64-byte strides, 0.41 ms for a cancer-sized table's 467 MB)
+  constexpr int NP = 4;
   __shared__ uint32_t s_wave[4];
-  __shared__ unsigned long long s_base;
+  __shared__ unsigned long long s_base, s_pool, s_pool_end;
   __shared__ unsigned long long s_part[6][4];
-  const uint64_t nbuckets = nslots / GF_SLOTS_PER_BUCKET;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t rounds = (nbuckets + stride - 1) / stride;  // whole blocks stay in the loop for the barriers
+  if (threadIdx.x == 0) s_pool = s_pool_end = 0;  // (read and written by thread 0 alone)
+  const uint64_t npairs = nslots / 2;
+  const uint64_t per_round = (uint64_t)gridDim.x * blockDim.x * NP;
+  const uint64_t rounds = (npairs + per_round - 1) / per_round;  // whole blocks stay in the loop for the barriers
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long sites = 0;
   uint32_t keys = 0, uniq = 0, dk = 0, high = 0, ds = 0;
   for (uint64_t it = 0; it < rounds; ++it) {
-    const uint64_t b = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t val[GF_SLOTS_PER_BUCKET], want[GF_SLOTS_PER_BUCKET], cnt_of[GF_SLOTS_PER_BUCKET];
+    const uint64_t p0 = it * per_round + (uint64_t)blockIdx.x * blockDim.x * NP + threadIdx.x;  // + 256 j
+    uint32_t val[2 * NP], want[2 * NP], cnt_of[2 * NP];
     uint32_t mine = 0;
-    uint64_t* base_slot = slots + b * GF_SLOTS_PER_BUCKET;
-    if (b < nbuckets) {
-      const uint4* q = (const uint4*)base_slot;
-      const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-      val[0] = q0.x; val[1] = q0.z; val[2] = q1.x; val[3] = q1.z;
-      val[4] = q2.x; val[5] = q2.z; val[6] = q3.x; val[7] = q3.z;
-    } else {
 #pragma unroll
-      for (int k = 0; k < GF_SLOTS_PER_BUCKET; ++k) val[k] = 0;
+    for (int j = 0; j < NP; ++j) {
+      const uint64_t p = p0 + 256u * j;
+      uint4 q = make_uint4(0, 0, 0, 0);
+      if (p < npairs) q = ((const uint4*)slots)[p];
+      val[2 * j] = q.x;
+      val[2 * j + 1] = q.z;
     }
 #pragma unroll
-    for (int k = 0; k < GF_SLOTS_PER_BUCKET; ++k) {
+    for (int k = 0; k < 2 * NP; ++k) {
       // a slot holds a count (two-pass build, or a key the one-pass build found more than once), or — one-pass
       // build — the site of a key claimed once: type UNIQUE already, count 1
       const bool claimed = ((val[k] & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE;
@@ -586,26 +774,36 @@ __global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uin
       if (w < wave) before += s_wave[w];
       total += s_wave[w];
     }
-    if (threadIdx.x == 0 && total) s_base = atomicAdd(stats + 6, (unsigned long long)total);
+    // Room in dupes[] by the granule: same-address atomics take their turns beyond the L2s, 5-14 ns each, and one
+    // per block and round (28 K of them on a cancer-sized table) was most of this kernel's 0.41 ms.  A block takes
+    // GF_DUPE_GRANULE entries at a time and hands them out itself; what is left of a granule that the next round
+    // does not fit in stays empty (the host sizes dupes[] for it).
+    if (threadIdx.x == 0 && total) {
+      if (s_pool + total > s_pool_end) {
+        const unsigned long long grab = total > GF_DUPE_GRANULE ? total : GF_DUPE_GRANULE;
+        s_pool = atomicAdd(stats + 6, grab);
+        s_pool_end = s_pool + grab;
+      }
+      s_base = s_pool;
+      s_pool += total;
+    }
     __syncthreads();
     uint32_t start = (uint32_t)(total ? s_base : 0ull) + before + incl - mine;
-    if (b < nbuckets) {
 #pragma unroll
-      for (int k = 0; k < GF_SLOTS_PER_BUCKET; ++k) {
-        const uint32_t c = cnt_of[k];
-        if (!c) continue;
-        uint32_t nv;
-        if (c == 1) {
-          if (((val[k] & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) continue;  // claimed with its site: final
-          nv = GF_TYPE_UNIQUE << GF_TYPE_SHIFT;
-        } else if (c <= GF_DUP_THRESHOLD) {
-          nv = (GF_TYPE_DUPES << GF_TYPE_SHIFT) | (c << GF_DUPE_COUNT_SHIFT) | (start & GF_DUPE_START_MASK);
-          start += c;
-        } else {
-          nv = GF_TYPE_HIGH << GF_TYPE_SHIFT;
-        }
-        *(uint32_t*)(base_slot + k) = (val[k] & GF_VAL_OVF) | nv;
+    for (int k = 0; k < 2 * NP; ++k) {
+      const uint32_t c = cnt_of[k];
+      if (!c) continue;  // (an empty slot; pairs beyond the table read as empty)
+      uint32_t nv;
+      if (c == 1) {
+        if (((val[k] & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_UNIQUE) continue;  // claimed with its site: final
+        nv = GF_TYPE_UNIQUE << GF_TYPE_SHIFT;
+      } else if (c <= GF_DUP_THRESHOLD) {
+        nv = (GF_TYPE_DUPES << GF_TYPE_SHIFT) | (c << GF_DUPE_COUNT_SHIFT) | (start & GF_DUPE_START_MASK);
+        start += c;
+      } else {
+        nv = GF_TYPE_HIGH << GF_TYPE_SHIFT;
       }
+      *(uint32_t*)(slots + 2 * (p0 + 256u * (k >> 1)) + (k & 1)) = (val[k] & GF_VAL_OVF) | nv;
     }
     __syncthreads();  // s_wave / s_base are rewritten in the next round
   }

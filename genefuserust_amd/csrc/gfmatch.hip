@@ -19,6 +19,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <functional>
+#include <unistd.h>
 
 #include "../../include/gfmatch.h"
 #include "gf_compact_kernels.h"
@@ -84,6 +86,62 @@ struct DevBuf {
     T* q = p;
     p = nullptr;
     return q;
+  }
+};
+
+// A few host threads that stay: gf_index_build's gather of the gene slices is 0.2 ms of copying, and starting
+// eight std::threads for it took 0.23 ms (r03, measured).  The pool is the process's, made on first use and never
+// taken down (its threads sleep on a condition variable; a process that forked gets a new one on its first job);
+// run() hands `f` to `n` of them and returns at once, wait() returns when they are all through with it.
+struct HostPool {
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  std::function<void()> job;
+  uint64_t gen = 0;
+  int wanted = 0, taken = 0, running = 0;
+  int n_threads = 0;
+  pid_t owner = 0;
+  static HostPool& get() {
+    static std::mutex make_mu;
+    static HostPool* pool = nullptr;
+    std::lock_guard<std::mutex> g(make_mu);
+    if (!pool || pool->owner != getpid()) {
+      pool = new HostPool();  // (never deleted: its threads may be asleep in it when the process ends)
+      pool->owner = getpid();
+    }
+    return *pool;
+  }
+  void worker() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_go.wait(lk, [&] { return gen != seen && taken < wanted; });
+      seen = gen;
+      ++taken;
+      std::function<void()> f = job;
+      lk.unlock();
+      f();
+      lk.lock();
+      if (--running == 0) cv_done.notify_all();
+    }
+  }
+  void run(int n, std::function<void()> f) {  // one job at a time (gf_index_build holds the staging block's lock)
+    std::unique_lock<std::mutex> lk(mu);
+    while (n_threads < n) {
+      std::thread(&HostPool::worker, this).detach();
+      ++n_threads;
+    }
+    job = std::move(f);
+    wanted = running = n;
+    taken = 0;
+    ++gen;
+    lk.unlock();
+    cv_go.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return running == 0; });
+    job = nullptr;
   }
 };
 
@@ -470,6 +528,11 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   static const bool timing = getenv("GF_BUILD_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t_start = now();
+  auto t_entry = now();
+  auto mark = [&](const char* what) {  // host clock only, no synchronisation
+    if (!timing) return;
+    fprintf(stderr, "[gf_index_build]   . %-40s at %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now() - t_entry).count());
+  };
   auto lap = [&](const char* what) {
     if (!timing) return;
     (void)hipDeviceSynchronize();
@@ -480,9 +543,17 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   std::unique_ptr<gf_index> ix(new gf_index());
   ix->device = dev;
   if (const char* e = getenv("GF_MAP_VARIANT")) ix->map_variant = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;  // experiments
-  hipDeviceProp_t prop;
-  GF_HIP(hipGetDeviceProperties(&prop, dev));
-  ix->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  {
+    static std::atomic<int> cus_of[64];  // (hipGetDeviceProperties is 0.1 ms a call: once per device and process)
+    int cus = dev < 64 ? cus_of[dev].load() : 0;
+    if (cus <= 0) {
+      hipDeviceProp_t prop;
+      GF_HIP(hipGetDeviceProperties(&prop, dev));
+      cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      if (dev < 64) cus_of[dev].store(cus);
+    }
+    ix->n_cus = cus;
+  }
 
   // --- host: upper-case the slices (indexer.rs:159), lay out the site-code space ---
   std::vector<uint32_t> gene_off((size_t)n_genes + 1, 0), lin_base((size_t)std::max(n_genes, 1), 0),
@@ -519,15 +590,17 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   const uint32_t ntiles = (uint32_t)((total + GF_TILE_BASES - 1) / GF_TILE_BASES);
   const size_t cat_bytes = (size_t)ntiles * GF_TILE_BASES + 64;
 
-  // Device blocks first, and the clears queued at once: they run while the host gathers the slices (r03: the host
-  // third of a rebuild — upper-casing two copies of every gene, a pageable 15 MB copy, the clears behind them — was
-  // 0.96 of 3.7 ms per cancer-shaped gene set).
+  // Device blocks first, and their clears queued at once: the device does them while the host gathers the slices.
   struct { uint8_t*& p; } d_cat{ix->d_cat};
   struct { uint32_t*& p; } d_goff{ix->d_gene_off};
-  DevBuf<unsigned long long> d_stats;
+  struct StatBlock {  // the statistics + the fill counts of the filter's partitions (32 bits each)
+    int dev; unsigned long long* p = nullptr;
+    ~StatBlock() { if (p) { (void)hipDeviceSynchronize(); block_free(dev, p); } }
+  } d_stats{dev};
+  const size_t stat_words = 8 + GF_FPARTS_MAX / 2;
   GF_HIP(block_alloc(dev, (void**)&ix->d_cat, cat_bytes));
   GF_HIP(block_alloc(dev, (void**)&ix->d_gene_off, ((size_t)n_genes + 1) * sizeof(uint32_t)));
-  GF_HIP(d_stats.alloc(8));
+  GF_HIP(block_alloc(dev, (void**)&d_stats.p, stat_words * sizeof(unsigned long long)));
   // both strands of the genes in site-code space + per-site uniqueness bits (diagonal
   // verification of the mapping kernel); padded so that a 256-base read hanging over
   // either end of the space stays inside the arrays
@@ -539,11 +612,14 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   GF_HIP(block_alloc(dev, (void**)&ix->d_gene_len, glen.size() * sizeof(uint32_t)));
   GF_HIP(hipMemsetAsync(ix->d_gdu, 0, 2 * gd_words * sizeof(uint32_t), 0));
   GF_HIP(hipMemsetAsync(ix->d_slots, 0, nslots * sizeof(uint64_t), 0));
-  GF_HIP(hipMemsetAsync(d_stats.p, 0, 8 * sizeof(unsigned long long), 0));
+  GF_HIP(hipMemsetAsync(d_stats.p, 0, stat_words * sizeof(unsigned long long), 0));
 
-  // The raw slices and the four small arrays into ONE pinned staging block (kept by the process, grow-only), a few
-  // host threads copying; then asynchronous copies to the device, where the bytes are upper-cased in place
-  // (indexer.rs:159).  The staging block is the process's: builds take turns at it.
+  mark("blocks taken, clears queued");
+
+  // The raw slices and the four small arrays go into ONE pinned staging block (kept by the process, grow-only) and
+  // from there to the device, where the bytes are upper-cased in place (indexer.rs:159).  The staging block is the
+  // process's: builds take turns at it.  (r03: the host third of a rebuild — upper-casing two copies of every gene,
+  // a pageable 15 MB copy, the clears behind them — was 0.96 of 3.7 ms per cancer-shaped gene set.)
   static std::mutex stage_mu;
   static uint8_t* stage = nullptr;
   static size_t stage_bytes = 0;
@@ -558,24 +634,56 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     GF_HIP(hipHostMalloc((void**)&stage, need_stage + need_stage / 4, hipHostMallocDefault));
     stage_bytes = need_stage + need_stage / 4;
   }
-  {
-    auto prep = [&](int32_t c) {
-      if (glen[(size_t)c]) memcpy(stage + gene_off[(size_t)c], gene_seqs[c], glen[(size_t)c]);
-    };
-    const int T = (int)std::min<uint64_t>(8, std::max<uint64_t>(1, total >> 20));  // a thread per MB, at most 8
-    if (T <= 1) {
-      for (int32_t c = 0; c < n_genes; ++c) prep(c);
-    } else {
-      std::atomic<int32_t> next{0};
-      std::vector<std::thread> th;
-      for (int t = 0; t < T; ++t)
-        th.emplace_back([&] {
-          for (int32_t c = next.fetch_add(1); c < n_genes; c = next.fetch_add(1)) prep(c);
-        });
-      for (auto& x : th) x.join();
+  // The gather goes megabyte by megabyte of the concatenation, a few threads of the host pool taking them in
+  // order, and a megabyte's way to the device (a kernel that pulls it over the bus and upper-cases it) is queued as
+  // soon as it is there.
+  const uint64_t CH = 1ull << 20;
+  const int nch = (int)((cat_bytes + CH - 1) / CH);
+  auto gather = [&](int k) {
+    const uint64_t b0 = (uint64_t)k * CH, b1 = std::min<uint64_t>(b0 + CH, cat_bytes);
+    if (b0 < total) {
+      // first gene that reaches into the chunk: last c with gene_off[c] <= b0
+      int32_t c = (int32_t)(std::upper_bound(gene_off.begin(), gene_off.begin() + n_genes, (uint32_t)b0) - gene_off.begin()) - 1;
+      for (c = std::max(c, 0); c < n_genes && gene_off[(size_t)c] < b1; ++c) {
+        const uint64_t g0 = gene_off[(size_t)c], g1 = g0 + glen[(size_t)c];
+        const uint64_t x0 = std::max(g0, b0), x1 = std::min(g1, b1);
+        if (x1 > x0) memcpy(stage + x0, gene_seqs[c] + (x0 - g0), (size_t)(x1 - x0));
+      }
     }
-    memset(stage + total, 0, cat_bytes - total);
+    if (b1 > total) memset(stage + std::max<uint64_t>(b0, total), 0, (size_t)(b1 - std::max<uint64_t>(b0, total)));
+  };
+  const int T = std::min(8, nch / 2);  // a thread per two megabytes, at most 8; none below four
+  std::atomic<int> next_chunk{0};
+  std::unique_ptr<std::atomic<int>[]> chunk_done(new std::atomic<int>[(size_t)nch]);
+  for (int k = 0; k < nch; ++k) chunk_done[(size_t)k].store(0, std::memory_order_relaxed);
+  struct PoolWait {  // (every return below, the failing ones too, waits for the threads: they use this frame)
+    HostPool* pool = nullptr;
+    ~PoolWait() { if (pool) pool->wait(); }
+  } pool_wait;
+  if (T > 0) {
+    pool_wait.pool = &HostPool::get();
+    pool_wait.pool->run(T, [&] {
+      for (int k = next_chunk.fetch_add(1); k < nch; k = next_chunk.fetch_add(1)) {
+        gather(k);
+        chunk_done[(size_t)k].store(1, std::memory_order_release);
+      }
+    });
   }
+  mark("gather threads started");
+  static const bool pull = getenv("GF_BUILD_DMA") == nullptr;  // (GF_BUILD_DMA=1: copies by the DMA engine + gf_k_upper_inplace, as before)
+  for (int k = 0; k < nch; ++k) {
+    if (T <= 0) gather(k);
+    else while (!chunk_done[(size_t)k].load(std::memory_order_acquire)) std::this_thread::yield();
+    const uint64_t b0 = (uint64_t)k * CH, b1 = std::min<uint64_t>(b0 + CH, cat_bytes);  // (both multiples of 16)
+    if (pull) {
+      hipLaunchKernelGGL(gf_k_upper_copy, dim3((unsigned)(((b1 - b0) / 16 + 255) / 256)), dim3(256), 0, 0,
+                         (const uint8_t*)stage + b0, d_cat.p + b0, (unsigned long long)((b1 - b0) / 16));
+      GF_HIP(hipGetLastError());
+    } else {
+      GF_HIP(hipMemcpyAsync(d_cat.p + b0, stage + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, 0));
+    }
+  }
+  mark("last chunk queued");
   uint32_t* meta = (uint32_t*)(stage + ((cat_bytes + 63) & ~(size_t)63));
   uint32_t* m_goff = meta; uint32_t* m_lb = m_goff + ((size_t)n_genes + 1);
   uint32_t* m_lh = m_lb + lin_base.size(); uint32_t* m_gl = m_lh + lin_base.size();
@@ -583,15 +691,16 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   memcpy(m_lb, lin_base.data(), lin_base.size() * sizeof(uint32_t));
   memcpy(m_lh, lin_hi.data(), lin_hi.size() * sizeof(uint32_t));
   memcpy(m_gl, glen.data(), glen.size() * sizeof(uint32_t));
-  lap("host: slices into the pinned block (clears queued)");
-  GF_HIP(hipMemcpyAsync(d_cat.p, stage, cat_bytes, hipMemcpyHostToDevice, 0));
+  lap("host: slices into the pinned block and on to the device (clears queued)");
   GF_HIP(hipMemcpyAsync(d_goff.p, m_goff, gene_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, 0));
   GF_HIP(hipMemcpyAsync(ix->d_lin_base, m_lb, lin_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, 0));
   GF_HIP(hipMemcpyAsync(ix->d_lin_hi, m_lh, lin_hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice, 0));
   GF_HIP(hipMemcpyAsync(ix->d_gene_len, m_gl, glen.size() * sizeof(uint32_t), hipMemcpyHostToDevice, 0));
-  hipLaunchKernelGGL(gf_k_upper_inplace, dim3((unsigned)std::min<size_t>((cat_bytes / 16 + 255) / 256, 4096)), dim3(256), 0, 0,
-                     d_cat.p, (unsigned long long)(cat_bytes / 16));
-  GF_HIP(hipGetLastError());
+  if (!pull) {
+    hipLaunchKernelGGL(gf_k_upper_inplace, dim3((unsigned)std::min<size_t>((cat_bytes / 16 + 255) / 256, 4096)), dim3(256), 0, 0,
+                       d_cat.p, (unsigned long long)(cat_bytes / 16));
+    GF_HIP(hipGetLastError());
+  }
 
   lap("alloc, memset, copies in");
   GfGenes G;
@@ -658,7 +767,9 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   };
   // the duplicate lists are sized before their keys are counted: every site could be in one (the block comes
   // from the cache of freed indexes in multi-CSV mode); the sweep that assigns them counts the keys on its way
-  const uint64_t dupes_cap = std::max<uint64_t>(std::min<uint64_t>(site_bound, (uint64_t)GF_DUPE_START_MASK + 1), 1);
+  // (+ a granule per block of the sweep that hands the lists out: gf_k_classify_assign)
+  const uint64_t dupes_cap = std::max<uint64_t>(std::min<uint64_t>(site_bound + (uint64_t)sweep_grid * GF_DUPE_GRANULE,
+                                                                   (uint64_t)GF_DUPE_START_MASK + 1), 1);
   GF_HIP(block_alloc(dev, (void**)&ix->d_dupes, dupes_cap * sizeof(uint32_t)));
   struct SideBlock { int dev; GfSideEntry* p = nullptr; ~SideBlock() { if (p) { (void)hipDeviceSynchronize(); block_free(dev, p); } } } d_side{dev};
   const uint64_t side_cap = std::max<uint64_t>(site_bound, 1);
@@ -666,9 +777,31 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   if (!two_pass) {
     if (int rc = make_filter(site_bound)) return rc;
     GF_HIP(block_alloc(dev, (void**)&d_side.p, side_cap * sizeof(GfSideEntry)));
+    // The filter first, by partitions and without global atomics (gf_index_kernels.h), in the side list's block,
+    // which the insert pass only then starts to fill.  (Filters beyond 8 MiB — whole-genome-sized indexes — and
+    // GF_FILTER_ATOMIC=1 keep the fill inside the insert pass.)
+    static const bool filter_atomic = getenv("GF_FILTER_ATOMIC") != nullptr;
+    bool filter_parted = false;
+    unsigned int* d_part_fill = (unsigned int*)(d_stats.p + 8);  // (cleared with the statistics)
+    if (ix->d_bloom && ntiles > 0 && !filter_atomic && bloom_words <= GF_FPARTS_MAX * GF_FSLICE_WORDS) {
+      const uint32_t nparts = (bloom_words + GF_FSLICE_WORDS - 1) / GF_FSLICE_WORDS;
+      const uint64_t room = side_cap * (sizeof(GfSideEntry) / sizeof(uint32_t)) / nparts;  // hashes per partition the block holds
+      const uint64_t want = 2 * ((total + total / 8) / nparts) + 1024;  // twice an even share of (a little over) one hash per base
+      const uint32_t part_cap = (uint32_t)std::min<uint64_t>(std::min(room, want), 0x7FFFFFFFull);
+      if (part_cap > 0) {
+        hipLaunchKernelGGL(gf_k_filter_scatter, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G, ix->d_bloom, bloom_words, nparts,
+                           (uint32_t*)d_side.p, part_cap, d_part_fill);
+        GF_HIP(hipGetLastError());
+        hipLaunchKernelGGL(gf_k_filter_build, dim3(nparts), dim3(1024), 0, 0, ix->d_bloom, bloom_words,
+                           (const uint32_t*)d_side.p, part_cap, (const unsigned int*)d_part_fill);
+        GF_HIP(hipGetLastError());
+        filter_parted = true;
+      }
+    }
     if (ntiles > 0) {
       hipLaunchKernelGGL(gf_k_index_insert, dim3(ntiles), dim3(GF_INDEX_THREADS), 0, 0, G, ix->d_slots, nbuckets, ix->d_gdu,
-                         ix->d_bloom, bloom_words, d_side.p, d_stats.p + 7, (unsigned long long)side_cap);
+                         filter_parted ? (uint32_t*)nullptr : ix->d_bloom, bloom_words, d_side.p, d_stats.p + 7,
+                         (unsigned long long)side_cap);
       GF_HIP(hipGetLastError());
     }
   } else if (ntiles > 0) {
@@ -676,14 +809,16 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
                        ix->d_slots, nbuckets, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     GF_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(gf_k_classify_assign, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
+  // (few blocks: each ends with seven atomics on the same seven addresses, 14 ns apiece and one after the other —
+  //  4096 blocks' worth was 60 us, more than a druggable-sized table's sweep itself)
+  hipLaunchKernelGGL(gf_k_classify_assign, dim3(std::min(sweep_grid, ix->n_cus * 4)), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
   GF_HIP(hipGetLastError());
   GF_HIP(hipMemcpy(stats, d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
   lap(two_pass ? "strands, count pass, list assignment + statistics" : "strands, insert pass (sites, flags, filter), list assignment + statistics");
-  const uint64_t n_dupe_sites = stats[5];
-  if (n_dupe_sites > (uint64_t)GF_DUPE_START_MASK)
+  const uint64_t dupes_extent = stats[6];  // (>= stats[5], the sites in the lists: granules end unused)
+  if (dupes_extent > dupes_cap)
     return fail(GF_ERR_CAPACITY, "too many duplicated sites for the 26-bit duplicate index");
-  GF_HIP(hipMemsetAsync(ix->d_dupes, 0xFF, std::max<uint64_t>(n_dupe_sites, 1) * sizeof(uint32_t), 0));
+  GF_HIP(hipMemsetAsync(ix->d_dupes, 0xFF, std::max<uint64_t>(dupes_extent, 1) * sizeof(uint32_t), 0));
   if (!two_pass) {
     n_side = stats[7];
     if (n_side > side_cap) return fail(GF_ERR_CAPACITY, "side list of the index build overflowed");
@@ -703,8 +838,10 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     }
     lap("fill pass (sites, unique flags, filter)");
   }
-  hipLaunchKernelGGL(gf_k_sort_dupes, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_dupes);
-  GF_HIP(hipGetLastError());
+  if (two_pass) {  // (the one-pass build sorts a list as its last site arrives: gf_k_index_side)
+    hipLaunchKernelGGL(gf_k_sort_dupes, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_dupes);
+    GF_HIP(hipGetLastError());
+  }
   GF_HIP(hipDeviceSynchronize());
   lap("list sort");
 
