@@ -184,8 +184,37 @@ def test_repeat_heavy_genes_through_the_side_list(gpu_device):
             n = len(sites[k])
             assert int(cnt[j]) == (n if n <= 5 else -2), (hex(k), n, int(cnt[j]))   # -2: the HIGH mark
             if 2 <= n <= 5:   # the list holds exactly the key's sites (as site codes: contig / position -> code)
-                got = sorted(int(lin_base[int(ctg[j, t])]) + int(pos[j, t]) for t in range(n))
+                got = [int(lin_base[int(ctg[j, t])]) + int(pos[j, t]) for t in range(n)]
+                # ... in ascending order of site code: the thread that brings a list's last site sorts it
+                # (gf_k_index_side), so the content is reproducible whatever the order of arrival
                 assert got == sorted(sites[k]), (hex(k), got, sorted(sites[k]))
+    finally:
+        ix.close()
+
+
+def test_filter_partition_overflow_goes_through_the_atomic(gpu_device):
+    """The presence filter is filled by hash partitions (gf_k_filter_scatter / gf_k_filter_build); a partition has
+    room for twice an even share of the hashes.  120 K bases of one letter put 120 K equal hashes into ONE of some
+    25 partitions: the excess takes the atomic path and the building block ORs over it — the filter still equals
+    the host rebuild word by word, with the poly-A key's bits in it."""
+    from genefuserust_amd import Indexer
+    rng = np.random.default_rng(4711)
+    def rnd(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n))
+    # (+ 150 slices of 20-45 bases: tiles of more than 62 genes take the kernel's search of the offsets per base
+    #  instead of the tile's own short list)
+    genes = [b"A" * 120000, rnd(90000), b"CA" * 20000] + [rnd(int(n)) for n in rng.integers(20, 46, size=150)]
+    ix = Indexer.from_gene_slices(genes)
+    ix.make_index()
+    try:
+        gdu, filt, lin_base = _export(ix, 0), _export(ix, 1), _export(ix, 2)
+        assert filt.shape[0] > 4 * 8192   # several partitions
+        even, flags, want_filter, sites = _expected(genes, lin_base, gdu.shape[0] // 2, filt.shape[0])
+        bad = np.nonzero(filt != want_filter)[0]
+        assert bad.size == 0, ("filter words differ", bad[:5])
+        assert (gdu[0::2] == even).all() and (gdu[1::2] == flags).all()
+        w, b = _filter_bits(0, filt.shape[0])   # the canonical 14-mer of A x 14 (and of T x 14)
+        assert int(filt[w]) & b == b
     finally:
         ix.close()
 
