@@ -154,6 +154,8 @@ def lib() -> C.CDLL:
     L.gf_fastq_index_device.restype = C.c_int
     L.gf_fastq_gather_device.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp, vp, i64, vp, vp, vp]
     L.gf_fastq_gather_device.restype = C.c_int
+    L.gf_fastq_gather_lean_device.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp, vp]
+    L.gf_fastq_gather_lean_device.restype = C.c_int
     L.gf_fast_merge_find_device.argtypes = [vp] * 7 + [i64, i32] + [vp] * 3
     L.gf_fast_merge_find_device.restype = C.c_int
     L.gf_fast_merge_write_device.argtypes = [vp] * 7 + [i64] + [vp] * 5
@@ -173,6 +175,8 @@ def lib() -> C.CDLL:
     L.gf_scan_pairs_retry_capacity.restype = i64
     L.gf_scan_pairs_device.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, i32, i64, i64, vp, i64, vp, vp, i64, vp, vp]
     L.gf_scan_pairs_device.restype = C.c_int
+    L.gf_scan_pairs_text_device.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, i32, i64, i64, vp, i64, vp, vp, i64, vp, vp]
+    L.gf_scan_pairs_text_device.restype = C.c_int
     L.gf_segment_mask_test.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
     L.gf_segment_mask_test.restype = C.c_int
     L.gf_index_export.argtypes = [vp, i32, vp, i64]

@@ -180,13 +180,19 @@ __device__ __forceinline__ uint4 gf_fq_splice16(uint4 a, uint4 b, int k) {
 // '!' (Phred 0), a longer one is cut: both are counted in *n_bad (the reference does not
 // check, and its fast_merge would panic on the short ones); a tile that holds such a record,
 // or that does not fit the caller's buffers, is copied a wavefront per record instead.
+// WITH_Q = false (r03 b): the qualities stay where they are — 1.5 GB per 10 M records that a few thousand hit records
+// and the merge's rare mismatching columns ever read — and `qual_off[r]` says where record r's quality line starts in
+// the text; a record whose quality line has another length than its sequence is counted in *n_bad as ever (the
+// caller then gathers with qualities: the in-place form has no room for the padding).
+template <bool WITH_Q>
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __restrict__ text,
                                                               const int64_t* __restrict__ nl_pos, int64_t n_newlines,
                                                               int64_t n_bytes, int64_t n_rec,
                                                               const int64_t* __restrict__ tile_offsets,
                                                               int64_t* __restrict__ offsets,
                                                               uint8_t* __restrict__ bases, uint8_t* __restrict__ quals,
-                                                              int64_t cap_bytes, unsigned long long* __restrict__ n_bad) {
+                                                              int64_t cap_bytes, unsigned long long* __restrict__ n_bad,
+                                                              int64_t* __restrict__ qual_off) {
   __shared__ int s_wave[4];
   __shared__ int64_t s_ss[GF_FQ_RTILE], s_qs[GF_FQ_RTILE];
   __shared__ int s_rel[GF_FQ_RTILE + 2], s_qlen[GF_FQ_RTILE];
@@ -208,10 +214,11 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __r
   const int64_t pos0 = tile_offsets[blockIdx.x];
   if (r < n_rec) {
     offsets[r] = pos0 + rel;
+    if (!WITH_Q) qual_off[r] = qs;
     if (r == n_rec - 1) offsets[n_rec] = pos0 + rel + len;
     if (qlen != len) {
       atomicAdd(n_bad, 1ull);
-      s_odd = 1;
+      if (WITH_Q) s_odd = 1;  // (the careful path is about the qualities' padding)
     }
   }
   s_ss[threadIdx.x] = ss; s_qs[threadIdx.x] = qs;
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __r
   if (threadIdx.x < 2) s_rel[GF_FQ_RTILE + threadIdx.x] = total;
   __syncthreads();
   const int64_t end = pos0 + total;
-  const bool aligned = (((uintptr_t)bases | (uintptr_t)quals) & 15u) == 0;
+  const bool aligned = (((uintptr_t)bases | (WITH_Q ? (uintptr_t)quals : (uintptr_t)0)) & 15u) == 0;
   if (!s_odd && end <= cap_bytes && aligned) {
     const int64_t c_hi = (end + 15) >> 4;
     for (int64_t c = (pos0 >> 4) + threadIdx.x; c < c_hi; c += GF_CTHREADS) {
@@ -239,19 +246,20 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __r
       const int64_t sa = s_ss[i] + (xb - s_rel[i]), qa = s_qs[i] + (xb - s_rel[i]);
       if (whole && s_rel[i + 1] >= xb + 16) {
         *(uint4*)(bases + b0) = gf_fq_load16(text + sa);
-        *(uint4*)(quals + b0) = gf_fq_load16(text + qa);
-      } else if (whole && s_rel[i + 2] >= xb + 16 && qa + 16 <= n_bytes) {
+        if (WITH_Q) *(uint4*)(quals + b0) = gf_fq_load16(text + qa);
+      } else if (whole && s_rel[i + 2] >= xb + 16 &&
+                 (WITH_Q ? qa + 16 <= n_bytes : (sa + 16 <= n_bytes && s_ss[i + 1] + 16 <= n_bytes))) {
         // (sa < qa: the sequence line's load cannot run off the text when the quality line's does not;
         //  the second record's loads start k bytes before its lines, inside the text)
         const int k = s_rel[i + 1] - xb;  // bytes of record i in this piece, 1 .. 15
         *(uint4*)(bases + b0) = gf_fq_splice16(gf_fq_load16(text + sa), gf_fq_load16(text + s_ss[i + 1] - k), k);
-        *(uint4*)(quals + b0) = gf_fq_splice16(gf_fq_load16(text + qa), gf_fq_load16(text + s_qs[i + 1] - k), k);
+        if (WITH_Q) *(uint4*)(quals + b0) = gf_fq_splice16(gf_fq_load16(text + qa), gf_fq_load16(text + s_qs[i + 1] - k), k);
       } else {
         for (int64_t b = lo; b < hi; ++b) {
           const int xx = (int)(b - pos0);
           while (s_rel[i + 1] <= xx) ++i;
           bases[b] = text[s_ss[i] + (xx - s_rel[i])];
-          quals[b] = text[s_qs[i] + (xx - s_rel[i])];
+          if (WITH_Q) quals[b] = text[s_qs[i] + (xx - s_rel[i])];
         }
       }
     }
@@ -265,7 +273,9 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_fq_gather(const uint8_t* __r
     const int ln = s_rel[i + 1] - s_rel[i], ql = s_qlen[i];
     if (dst + ln > cap_bytes) continue;  // (the caller's buffers are too small: offsets still tell how much is needed)
     gf_fq_copy_line(bases + dst, text + s_ss[i], ln, lane);
-    const uint8_t* qsrc = text + s_qs[i];
-    for (int k = lane; k < ln; k += 64) quals[dst + k] = k < ql ? qsrc[k] : (uint8_t)'!';
+    if (WITH_Q) {
+      const uint8_t* qsrc = text + s_qs[i];
+      for (int k = lane; k < ln; k += 64) quals[dst + k] = k < ql ? qsrc[k] : (uint8_t)'!';
+    }
   }
 }

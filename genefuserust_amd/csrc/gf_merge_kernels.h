@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_MF_WAVES_PER_SIMD : 3) void gf_k
                                                               const uint8_t* __restrict__ r_bases,
                                                               const uint8_t* __restrict__ r_quals,
                                                               const int64_t* __restrict__ r_off, int64_t n,
+    const int64_t* __restrict__ l_qoff, const int64_t* __restrict__ r_qoff,  /* where a read's qualities start in l_quals / r_quals; null: at its bases' offset */
                                                               int32_t* __restrict__ out_len,
                                                               int32_t* __restrict__ out_diff) {
   constexpr int TILE_BYTES = 64 * 16 * PW;
@@ -220,9 +221,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_MF_WAVES_PER_SIMD : 3) void gf_k
         int found = 0, diff = 0;
         if (lim64 >= GF_MERGE_MIN_OVERLAP) {
           const uint8_t* s1 = l_bases + lo1;
-          const uint8_t* q1 = l_quals + lo1;
+          const uint8_t* q1 = l_quals + (l_qoff ? l_qoff[p] : lo1);
           const uint8_t* s2 = r_bases + lo2;
-          const uint8_t* q2 = r_quals + lo2;
+          const uint8_t* q2 = r_quals + (r_qoff ? r_qoff[p] : lo2);
           bool bytes_path = oversize || len1_64 > 16 * PW || len2_64 > 16 * PW;
           const int len1 = (int)len1_64, len2 = (int)len2_64;
           if (!bytes_path) {
@@ -346,13 +347,14 @@ __global__ __launch_bounds__(256) void gf_k_merge_find_bytes(const uint8_t* __re
                                                              const uint8_t* __restrict__ r_bases,
                                                              const uint8_t* __restrict__ r_quals,
                                                              const int64_t* __restrict__ r_off, int64_t n,
+    const int64_t* __restrict__ l_qoff, const int64_t* __restrict__ r_qoff,  /* where a read's qualities start in l_quals / r_quals; null: at its bases' offset */
                                                              int32_t* __restrict__ out_len,
                                                              int32_t* __restrict__ out_diff) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
     const int len1 = (int)(l_off[p + 1] - l_off[p]), len2 = (int)(r_off[p + 1] - r_off[p]);
     int diff = 0;
-    const int found = gf_merge_find_bytes(l_bases + l_off[p], l_quals + l_off[p], len1, r_bases + r_off[p],
-                                          r_quals + r_off[p], len2, diff);
+    const int found = gf_merge_find_bytes(l_bases + l_off[p], l_quals + (l_qoff ? l_qoff[p] : l_off[p]), len1, r_bases + r_off[p],
+                                          r_quals + (r_qoff ? r_qoff[p] : r_off[p]), len2, diff);
     out_len[p] = found ? len1 - found + len2 : 0;
     out_diff[p] = diff;
   }
@@ -432,12 +434,13 @@ __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restric
                                                         const uint8_t* __restrict__ r_bases,
                                                         const uint8_t* __restrict__ r_quals,
                                                         const int64_t* __restrict__ r_off, int64_t n,
+    const int64_t* __restrict__ l_qoff, const int64_t* __restrict__ r_qoff,  /* where a read's qualities start in l_quals / r_quals; null: at its bases' offset */
                                                         const int32_t* __restrict__ in_len,
                                                         const int64_t* __restrict__ out_pos,
                                                         uint8_t* __restrict__ out_bases,
                                                         uint8_t* __restrict__ out_quals) {
   __shared__ unsigned int s_cnt;
-  __shared__ int64_t s_l[256], s_r[256], s_dst[256];
+  __shared__ int64_t s_l[256], s_r[256], s_dst[256], s_lq[256], s_rq[256];
   __shared__ int s_len1[256], s_len2[256], s_mlen[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
@@ -452,6 +455,8 @@ __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restric
       const int64_t lo = l_off[p0], ro = r_off[p0];
       s_l[slot] = lo;
       s_r[slot] = ro;
+      s_lq[slot] = l_qoff ? l_qoff[p0] : lo;
+      s_rq[slot] = r_qoff ? r_qoff[p0] : ro;
       s_len1[slot] = (int)(l_off[p0 + 1] - lo);
       s_len2[slot] = (int)(r_off[p0 + 1] - ro);
       s_mlen[slot] = ml;
@@ -469,9 +474,9 @@ __global__ __launch_bounds__(256) void gf_k_merge_write(const uint8_t* __restric
       const int mmax = mla > mlb ? mla : mlb;
       for (int k0 = 0; k0 < mmax; k0 += 320) {
         GfMergeBytes ga, gb;
-        gf_mw_load(ga, l_bases + s_l[e0], l_quals + s_l[e0], r_bases + s_r[e0], r_quals + s_r[e0], len1a, len2a, mla,
+        gf_mw_load(ga, l_bases + s_l[e0], l_quals + s_lq[e0], r_bases + s_r[e0], r_quals + s_rq[e0], len1a, len2a, mla,
                    offa, k0, lane);
-        gf_mw_load(gb, l_bases + s_l[ex], l_quals + s_l[ex], r_bases + s_r[ex], r_quals + s_r[ex], len1b, len2b, mlb,
+        gf_mw_load(gb, l_bases + s_l[ex], l_quals + s_lq[ex], r_bases + s_r[ex], r_quals + s_rq[ex], len1b, len2b, mlb,
                    offb, k0, lane);
         __builtin_amdgcn_sched_barrier(0);  // both pairs' loads before anybody's stores
         gf_mw_store(ga, out_bases + s_dst[e0], out_quals + s_dst[e0], len1a, mla, offa, k0, lane);
@@ -579,11 +584,12 @@ __global__ __launch_bounds__(256) void gf_k_merge_write_bases(const uint8_t* __r
                                                               const uint8_t* __restrict__ r_bases,
                                                               const uint8_t* __restrict__ r_quals,
                                                               const int64_t* __restrict__ r_off, int64_t n,
+    const int64_t* __restrict__ l_qoff, const int64_t* __restrict__ r_qoff,  /* where a read's qualities start in l_quals / r_quals; null: at its bases' offset */
                                                               const int32_t* __restrict__ in_len,
                                                               const int64_t* __restrict__ out_pos,
                                                               uint8_t* __restrict__ out_bases) {
   __shared__ unsigned int s_cnt;
-  __shared__ int64_t s_l[256], s_r[256], s_dst[256];
+  __shared__ int64_t s_l[256], s_r[256], s_dst[256], s_lq[256], s_rq[256];
   __shared__ int s_len1[256], s_len2[256], s_mlen[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
@@ -598,6 +604,8 @@ __global__ __launch_bounds__(256) void gf_k_merge_write_bases(const uint8_t* __r
       const int64_t lo = l_off[p0], ro = r_off[p0];
       s_l[slot] = lo;
       s_r[slot] = ro;
+      s_lq[slot] = l_qoff ? l_qoff[p0] : lo;
+      s_rq[slot] = r_qoff ? r_qoff[p0] : ro;
       s_len1[slot] = (int)(l_off[p0 + 1] - lo);
       s_len2[slot] = (int)(r_off[p0 + 1] - ro);
       s_mlen[slot] = ml;
@@ -613,9 +621,9 @@ __global__ __launch_bounds__(256) void gf_k_merge_write_bases(const uint8_t* __r
       const int len1b = s_len1[ex], len2b = s_len2[ex], mlb = two ? s_mlen[ex] : 0;
       const int mmax = mla > mlb ? mla : mlb;
       for (int k0 = 0; k0 < mmax; k0 += 512) {
-        gf_mwb_piece(l_bases + s_l[e0], l_quals + s_l[e0], len1a, r_bases + s_r[e0], r_quals + s_r[e0], len2a, mla,
+        gf_mwb_piece(l_bases + s_l[e0], l_quals + s_lq[e0], len1a, r_bases + s_r[e0], r_quals + s_rq[e0], len2a, mla,
                      mla - len2a, k0 + 8 * lane, out_bases + s_dst[e0]);
-        gf_mwb_piece(l_bases + s_l[ex], l_quals + s_l[ex], len1b, r_bases + s_r[ex], r_quals + s_r[ex], len2b, mlb,
+        gf_mwb_piece(l_bases + s_l[ex], l_quals + s_lq[ex], len1b, r_bases + s_r[ex], r_quals + s_rq[ex], len2b, mlb,
                      mlb - len2b, k0 + 8 * lane, out_bases + s_dst[ex]);
       }
     }

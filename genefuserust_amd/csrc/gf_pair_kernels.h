@@ -33,6 +33,11 @@ static_assert(GF_PTILE == GF_CTHREADS, "the pair kernels take one pair per threa
 struct GfPairIn {
   const uint8_t *l_bases, *l_quals, *r_bases, *r_quals;
   const int64_t *l_off, *r_off;
+  // Where a read's qualities start in l_quals / r_quals; null: at its bases' offset (the layout gf_fastq_gather_device
+  // writes).  Not null: the qualities were left where they are — l_quals is the FASTQ text itself and l_qoff[p]
+  // the start of record p's quality line (gf_fastq_gather_lean_device) — and are fetched for the few reads that
+  // need them: mismatching columns of an overlap, reverse-complement retries, hit records.
+  const int64_t *l_qoff, *r_qoff;
   const uint8_t* m_bases;            // merged reads, back to back (their qualities: gf_pair_qual)
   const int64_t* m_off;              // int64[n+1]: an empty slot for a pair that did not merge
   const int32_t* m_len;              // 0 = not merged
@@ -70,10 +75,10 @@ __device__ __forceinline__ void gf_pair_candidate(const GfPairIn& P, int64_t p, 
     bases = P.m_bases + o; quals = nullptr; len = P.m_len[p]; cnt = P.m_len[p] > 0 ? P.cM[j] : (uint8_t)0; m = P.mM + 2 * j;
   } else if (s == 1) {
     const int64_t o = P.l_off[p];
-    bases = P.l_bases + o; quals = P.l_quals + o; len = (int32_t)(P.l_off[p + 1] - o); cnt = P.c1[p]; m = P.m1 + 2 * p;
+    bases = P.l_bases + o; quals = P.l_qoff ? nullptr : P.l_quals + o; len = (int32_t)(P.l_off[p + 1] - o); cnt = P.c1[p]; m = P.m1 + 2 * p;
   } else {
     const int64_t o = P.r_off[p];
-    bases = P.r_bases + o; quals = P.r_quals + o; len = (int32_t)(P.r_off[p + 1] - o); cnt = P.c2[p]; m = P.m2 + 2 * p;
+    bases = P.r_bases + o; quals = P.r_qoff ? nullptr : P.r_quals + o; len = (int32_t)(P.r_off[p + 1] - o); cnt = P.c2[p]; m = P.m2 + 2 * p;
   }
 }
 
@@ -92,10 +97,20 @@ __device__ __forceinline__ GfPairQual gf_pair_qual(const GfPairIn& P, int64_t p,
   Q.len1 = Q.len2 = Q.mlen = 0;
   if (s == 0 && !quals) {
     const int64_t lo = P.l_off[p], ro = P.r_off[p];
-    Q.s1 = P.l_bases + lo; Q.q1 = P.l_quals + lo; Q.len1 = (int)(P.l_off[p + 1] - lo);
-    Q.s2 = P.r_bases + ro; Q.q2 = P.r_quals + ro; Q.len2 = (int)(P.r_off[p + 1] - ro);
+    Q.s1 = P.l_bases + lo; Q.q1 = P.l_quals + (P.l_qoff ? P.l_qoff[p] : lo); Q.len1 = (int)(P.l_off[p + 1] - lo);
+    Q.s2 = P.r_bases + ro; Q.q2 = P.r_quals + (P.r_qoff ? P.r_qoff[p] : ro); Q.len2 = (int)(P.r_off[p + 1] - ro);
     Q.mlen = P.m_len[p];
+  } else if (s == 1 && !quals) {  // (qualities left in the text: gf_pair_candidate hands out no pointer)
+    Q.q = P.l_quals + P.l_qoff[p];
+  } else if (s == 2 && !quals) {
+    Q.q = P.r_quals + P.r_qoff[p];
   }
+  return Q;
+}
+__device__ __forceinline__ GfPairQual gf_pair_qual_none() {  // (a lane without a read to write)
+  GfPairQual Q;
+  Q.q = Q.s1 = Q.q1 = Q.s2 = Q.q2 = nullptr;
+  Q.len1 = Q.len2 = Q.mlen = 0;
   return Q;
 }
 
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_retry_write(
     const bool mine = p < n && st[3 * p + s] == GF_PS_RETRY;
     const uint8_t* b = nullptr; const uint8_t* q = nullptr; int32_t len = 0; uint8_t cnt; const gf_seqmatch* m;
     bool fits = false;
-    GfPairQual Q = gf_pair_qual(P, 0, 1, nullptr);
+    GfPairQual Q = gf_pair_qual_none();
     if (mine) {
       gf_pair_candidate(P, p, s, b, q, len, cnt, m);
       fits = k_out < cap_reads && b_out + len <= cap_bytes;
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_final_write(
     const bool mine = p < n && st[3 * p + s] != GF_PS_NONE && gf_pair_final(P, p, s, st, slot_of, cR, mR, slot);
     const uint8_t* b = nullptr; const uint8_t* q = nullptr; int32_t len = 0; uint8_t cnt; const gf_seqmatch* m;
     bool bytes_fit = false;
-    GfPairQual Q = gf_pair_qual(P, 0, 1, nullptr);
+    GfPairQual Q = gf_pair_qual_none();
     if (mine) {
       gf_pair_candidate(P, p, s, b, q, len, cnt, m);
       if (slot >= 0) {  // the match is on the reverse complement: its bases, its mapping

@@ -125,18 +125,27 @@ struct HostPool {
       if (--running == 0) cv_done.notify_all();
     }
   }
-  void run(int n, std::function<void()> f) {  // one job at a time (gf_index_build holds the staging block's lock)
+  // one job at a time (gf_index_build holds the staging block's lock); returns how many threads took it on —
+  // fewer than asked for on a host that will not start another thread, 0: do it yourself, nothing to wait() for
+  int run(int n, std::function<void()> f) {
     std::unique_lock<std::mutex> lk(mu);
     while (n_threads < n) {
-      std::thread(&HostPool::worker, this).detach();
+      try {
+        std::thread(&HostPool::worker, this).detach();
+      } catch (...) {
+        break;
+      }
       ++n_threads;
     }
+    n = std::min(n, n_threads);
+    if (n <= 0) return 0;
     job = std::move(f);
     wanted = running = n;
     taken = 0;
     ++gen;
     lk.unlock();
     cv_go.notify_all();
+    return n;
   }
   void wait() {
     std::unique_lock<std::mutex> lk(mu);
@@ -660,19 +669,25 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     HostPool* pool = nullptr;
     ~PoolWait() { if (pool) pool->wait(); }
   } pool_wait;
+  bool pooled = false;
   if (T > 0) {
-    pool_wait.pool = &HostPool::get();
-    pool_wait.pool->run(T, [&] {
-      for (int k = next_chunk.fetch_add(1); k < nch; k = next_chunk.fetch_add(1)) {
-        gather(k);
-        chunk_done[(size_t)k].store(1, std::memory_order_release);
-      }
-    });
+    try {  // (a host that cannot start another thread gathers on this one)
+      HostPool& hp = HostPool::get();
+      pooled = hp.run(T, [&] {
+        for (int k = next_chunk.fetch_add(1); k < nch; k = next_chunk.fetch_add(1)) {
+          gather(k);
+          chunk_done[(size_t)k].store(1, std::memory_order_release);
+        }
+      }) > 0;
+      if (pooled) pool_wait.pool = &hp;
+    } catch (...) {  // (bad_alloc from the job's std::function, at worst: nothing was started)
+      pooled = false;
+    }
   }
   mark("gather threads started");
   static const bool pull = getenv("GF_BUILD_DMA") == nullptr;  // (GF_BUILD_DMA=1: copies by the DMA engine + gf_k_upper_inplace, as before)
   for (int k = 0; k < nch; ++k) {
-    if (T <= 0) gather(k);
+    if (!pooled) gather(k);
     else while (!chunk_done[(size_t)k].load(std::memory_order_acquire)) std::this_thread::yield();
     const uint64_t b0 = (uint64_t)k * CH, b1 = std::min<uint64_t>(b0 + CH, cat_bytes);  // (both multiples of 16)
     if (pull) {
@@ -1792,10 +1807,12 @@ int gf_readmatch_order(int32_t a_break, int64_t a_len, const char* a_name, int64
 }
 
 // ---- SequenceReadPair::fast_merge on the device ----
-int gf_fast_merge_find_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
-                              const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,
-                              const void* d_r_offsets, int64_t n, int32_t max_read_len, void* d_out_len,
-                              void* d_out_diff, void* stream) {
+// (d_l_qoff / d_r_qoff: where each read's qualities start in d_l_quals / d_r_quals — the FASTQ text, when the
+//  qualities were left in it; null = at the bases' offsets)
+static int merge_find_impl(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
+                           const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,
+                           const void* d_r_offsets, int64_t n, int32_t max_read_len, void* d_out_len,
+                           void* d_out_diff, void* stream, const void* d_l_qoff, const void* d_r_qoff) {
   if (!idx || n < 0 || max_read_len < 0) return fail(GF_ERR_ARG, "null index, negative n or max_read_len");
   if (n == 0) return GF_OK;
   if (!d_l_bases || !d_l_quals || !d_l_offsets || !d_r_bases || !d_r_quals || !d_r_offsets || !d_out_len ||
@@ -1806,9 +1823,10 @@ int gf_fast_merge_find_device(const gf_index* idx, const void* d_l_bases, const 
   const uint8_t* lb = (const uint8_t*)d_l_bases; const uint8_t* lq = (const uint8_t*)d_l_quals;
   const uint8_t* rb = (const uint8_t*)d_r_bases; const uint8_t* rq = (const uint8_t*)d_r_quals;
   const int64_t* lo = (const int64_t*)d_l_offsets; const int64_t* ro = (const int64_t*)d_r_offsets;
+  const int64_t* lqo = (const int64_t*)d_l_qoff; const int64_t* rqo = (const int64_t*)d_r_qoff;
   const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 32);
   if (max_read_len > 256) {  // beyond the packed kernels' word budget: the byte loop for every pair
-    hipLaunchKernelGGL(gf_k_merge_find_bytes, dim3(grid), dim3(256), 0, st, lb, lq, lo, rb, rq, ro, n,
+    hipLaunchKernelGGL(gf_k_merge_find_bytes, dim3(grid), dim3(256), 0, st, lb, lq, lo, rb, rq, ro, n, lqo, rqo,
                        (int32_t*)d_out_len, (int32_t*)d_out_diff);
     GF_HIP(hipGetLastError());
     return GF_OK;
@@ -1816,19 +1834,28 @@ int gf_fast_merge_find_device(const gf_index* idx, const void* d_l_bases, const 
   // groups of 64 pairs per wavefront, each packing its own spans into LDS
   const int g2 = (int)std::min<int64_t>((n + 255) / 256, (int64_t)idx->n_cus * 16);
   if (max_read_len <= 160)
-    hipLaunchKernelGGL((gf_k_merge_find_stream<10>), dim3(g2), dim3(256), 0, st, lb, lq, lo, rb, rq, ro, n,
+    hipLaunchKernelGGL((gf_k_merge_find_stream<10>), dim3(g2), dim3(256), 0, st, lb, lq, lo, rb, rq, ro, n, lqo, rqo,
                        (int32_t*)d_out_len, (int32_t*)d_out_diff);
   else
-    hipLaunchKernelGGL((gf_k_merge_find_stream<16>), dim3(g2), dim3(256), 0, st, lb, lq, lo, rb, rq, ro, n,
+    hipLaunchKernelGGL((gf_k_merge_find_stream<16>), dim3(g2), dim3(256), 0, st, lb, lq, lo, rb, rq, ro, n, lqo, rqo,
                        (int32_t*)d_out_len, (int32_t*)d_out_diff);
   GF_HIP(hipGetLastError());
   return GF_OK;
 }
 
-int gf_fast_merge_write_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
-                               const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,
-                               const void* d_r_offsets, int64_t n, const void* d_len, const void* d_out_pos,
-                               void* d_out_bases, void* d_out_quals, void* stream) {
+int gf_fast_merge_find_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
+                              const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,
+                              const void* d_r_offsets, int64_t n, int32_t max_read_len, void* d_out_len,
+                              void* d_out_diff, void* stream) {
+  return merge_find_impl(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, max_read_len,
+                         d_out_len, d_out_diff, stream, nullptr, nullptr);
+}
+
+static int merge_write_impl(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
+                            const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,
+                            const void* d_r_offsets, int64_t n, const void* d_len, const void* d_out_pos,
+                            void* d_out_bases, void* d_out_quals, void* stream, const void* d_l_qoff,
+                            const void* d_r_qoff) {
   if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
   if (n == 0) return GF_OK;
   if (!d_l_bases || !d_l_quals || !d_l_offsets || !d_r_bases || !d_r_quals || !d_r_offsets || !d_len ||
@@ -1839,15 +1866,25 @@ int gf_fast_merge_write_device(const gf_index* idx, const void* d_l_bases, const
   if (d_out_quals)
     hipLaunchKernelGGL(gf_k_merge_write, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_l_bases,
                        (const uint8_t*)d_l_quals, (const int64_t*)d_l_offsets, (const uint8_t*)d_r_bases,
-                       (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int32_t*)d_len,
+                       (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int64_t*)d_l_qoff,
+                       (const int64_t*)d_r_qoff, (const int32_t*)d_len,
                        (const int64_t*)d_out_pos, (uint8_t*)d_out_bases, (uint8_t*)d_out_quals);
   else  // the bases alone (gf_scan_pairs_device)
     hipLaunchKernelGGL(gf_k_merge_write_bases, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_l_bases,
                        (const uint8_t*)d_l_quals, (const int64_t*)d_l_offsets, (const uint8_t*)d_r_bases,
-                       (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int32_t*)d_len,
+                       (const uint8_t*)d_r_quals, (const int64_t*)d_r_offsets, n, (const int64_t*)d_l_qoff,
+                       (const int64_t*)d_r_qoff, (const int32_t*)d_len,
                        (const int64_t*)d_out_pos, (uint8_t*)d_out_bases);
   GF_HIP(hipGetLastError());
   return GF_OK;
+}
+
+int gf_fast_merge_write_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals,
+                               const void* d_l_offsets, const void* d_r_bases, const void* d_r_quals,
+                               const void* d_r_offsets, int64_t n, const void* d_len, const void* d_out_pos,
+                               void* d_out_bases, void* d_out_quals, void* stream) {
+  return merge_write_impl(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, d_len, d_out_pos,
+                          d_out_bases, d_out_quals, stream, nullptr, nullptr);
 }
 
 int gf_fast_merge_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
@@ -1945,9 +1982,10 @@ int gf_fastq_index_device(const gf_index* idx, const void* d_text, int64_t n_byt
   return GF_OK;
 }
 
-int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_bytes, const void* d_nl_pos,
-                           int64_t n_newlines, int64_t n_records, void* d_offsets, void* d_bases, void* d_quals,
-                           int64_t cap_bytes, void* d_n_bad, void* d_workspace, void* stream) {
+// (d_qual_off != null: the lean form — no qualities copied, d_qual_off[r] = where record r's quality line starts)
+static int fastq_gather_impl(const gf_index* idx, const void* d_text, int64_t n_bytes, const void* d_nl_pos,
+                             int64_t n_newlines, int64_t n_records, void* d_offsets, void* d_bases, void* d_quals,
+                             int64_t cap_bytes, void* d_n_bad, void* d_workspace, void* stream, void* d_qual_off) {
   if (!idx || n_bytes < 0 || n_newlines < 0 || n_records < 0 || cap_bytes < 0)
     return fail(GF_ERR_ARG, "null index or negative size");
   if (!d_offsets || !d_n_bad || !d_workspace) return fail(GF_ERR_ARG, "null device pointer");
@@ -1960,7 +1998,7 @@ int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_by
     GF_HIP(hipMemsetAsync(d_offsets, 0, sizeof(int64_t), st));
     return GF_OK;
   }
-  if (!d_text || !d_nl_pos || (cap_bytes > 0 && (!d_bases || !d_quals))) return fail(GF_ERR_ARG, "null device pointer");
+  if (!d_text || !d_nl_pos || (cap_bytes > 0 && (!d_bases || (!d_quals && !d_qual_off)))) return fail(GF_ERR_ARG, "null device pointer");
   const int64_t ntiles = (n_records + GF_FQ_RTILE - 1) / GF_FQ_RTILE;
   if (ntiles >= fq_tiles(n_bytes)) return fail(GF_ERR_ARG, "n_records impossible for a text of n_bytes");
   uintptr_t w = ((uintptr_t)d_workspace + 15) & ~(uintptr_t)15;
@@ -1970,11 +2008,31 @@ int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_by
   hipLaunchKernelGGL(gf_k_fq_lens, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const int64_t*)d_nl_pos, n_newlines,
                      n_bytes, n_records, tile_counts);
   launch_scan(st, ntiles, tile_counts, tile_offsets, total);
-  hipLaunchKernelGGL(gf_k_fq_gather, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text,
-                     (const int64_t*)d_nl_pos, n_newlines, n_bytes, n_records, tile_offsets, (int64_t*)d_offsets,
-                     (uint8_t*)d_bases, (uint8_t*)d_quals, cap_bytes, (unsigned long long*)d_n_bad);
+  if (d_qual_off)
+    hipLaunchKernelGGL((gf_k_fq_gather<false>), dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text,
+                       (const int64_t*)d_nl_pos, n_newlines, n_bytes, n_records, tile_offsets, (int64_t*)d_offsets,
+                       (uint8_t*)d_bases, (uint8_t*)nullptr, cap_bytes, (unsigned long long*)d_n_bad, (int64_t*)d_qual_off);
+  else
+    hipLaunchKernelGGL((gf_k_fq_gather<true>), dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, (const uint8_t*)d_text,
+                       (const int64_t*)d_nl_pos, n_newlines, n_bytes, n_records, tile_offsets, (int64_t*)d_offsets,
+                       (uint8_t*)d_bases, (uint8_t*)d_quals, cap_bytes, (unsigned long long*)d_n_bad, (int64_t*)nullptr);
   GF_HIP(hipGetLastError());
   return GF_OK;
+}
+
+int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_bytes, const void* d_nl_pos,
+                           int64_t n_newlines, int64_t n_records, void* d_offsets, void* d_bases, void* d_quals,
+                           int64_t cap_bytes, void* d_n_bad, void* d_workspace, void* stream) {
+  return fastq_gather_impl(idx, d_text, n_bytes, d_nl_pos, n_newlines, n_records, d_offsets, d_bases, d_quals, cap_bytes,
+                           d_n_bad, d_workspace, stream, nullptr);
+}
+
+int gf_fastq_gather_lean_device(const gf_index* idx, const void* d_text, int64_t n_bytes, const void* d_nl_pos,
+                                int64_t n_newlines, int64_t n_records, void* d_offsets, void* d_bases, int64_t cap_bytes,
+                                void* d_qual_off, void* d_n_bad, void* d_workspace, void* stream) {
+  if (!d_qual_off) return fail(GF_ERR_ARG, "null quality offsets");
+  return fastq_gather_impl(idx, d_text, n_bytes, d_nl_pos, n_newlines, n_records, d_offsets, d_bases, nullptr, cap_bytes,
+                           d_n_bad, d_workspace, stream, d_qual_off);
 }
 
 // ---- the pair policy of scan_pair_end for a whole pack, device resident (gf_pair_kernels.h) ----
@@ -1990,11 +2048,11 @@ int gf_index_set_gene_reversed(gf_index* idx, const uint8_t* gene_reversed, int3
 
 int64_t gf_scan_pairs_retry_capacity(int64_t n) { return n < 0 ? 0 : std::max<int64_t>(4096, n / 4); }
 
-int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
-                         int64_t l_bytes, const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets,
-                         int64_t r_bytes, int64_t n, int32_t max_read_len, int64_t pair_id_base, int64_t retry_cap,
-                         void* d_hits, int64_t hits_cap, void* d_hit_bases, void* d_hit_quals, int64_t hit_bytes_cap,
-                         void* d_totals, void* stream) {
+static int scan_pairs_impl(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
+                           int64_t l_bytes, const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets,
+                           int64_t r_bytes, int64_t n, int32_t max_read_len, int64_t pair_id_base, int64_t retry_cap,
+                           void* d_hits, int64_t hits_cap, void* d_hit_bases, void* d_hit_quals, int64_t hit_bytes_cap,
+                           void* d_totals, void* stream, const void* d_l_qoff, const void* d_r_qoff) {
   if (!idx || n < 0 || l_bytes < 0 || r_bytes < 0 || hits_cap < 0 || hit_bytes_cap < 0 || max_read_len < 0)
     return fail(GF_ERR_ARG, "null index or negative size");
   if (!d_totals) return fail(GF_ERR_ARG, "null totals");
@@ -2056,8 +2114,8 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   GF_HIP(hipMemsetAsync(scal, 0, 256, st));
 
   // 1. fast_merge: lengths, then the slots of the merged reads (exclusive scan), then the reads
-  rc = gf_fast_merge_find_device(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, max_read_len,
-                                 m_len, m_diff, stream);
+  rc = merge_find_impl(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, max_read_len,
+                       m_len, m_diff, stream, d_l_qoff, d_r_qoff);
   if (rc != GF_OK) return rc;
   // scalars: [0] merged bytes, [1] retries, [2] retry bytes, [3] hits, [4] hit bytes, [5] merged pairs
   hipLaunchKernelGGL(gf_k_len_tile_sums, dim3((unsigned)nctiles), dim3(GF_CTHREADS), 0, st, (const int32_t*)m_len, n, tcA, tcB);
@@ -2067,8 +2125,8 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   hipLaunchKernelGGL(gf_k_len_tail, dim3((unsigned)std::min<int64_t>((n + 256) / 256, 2048)), dim3(256), 0, st,
                      (const int64_t*)(scal + 5), (const int64_t*)(scal + 0), n, c_off);
   GF_HIP(hipGetLastError());
-  rc = gf_fast_merge_write_device(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, m_len, m_off,
-                                  mb, nullptr, stream);
+  rc = merge_write_impl(idx, d_l_bases, d_l_quals, d_l_offsets, d_r_bases, d_r_quals, d_r_offsets, n, m_len, m_off,
+                        mb, nullptr, stream, d_l_qoff, d_r_qoff);
   if (rc != GF_OK) return rc;
   // 2. the merged reads; R1 and R2 of the pairs that did not merge (in place, the others skipped)
   rc = map_reads_device_impl(idx, mb, c_off, n, (int32_t)std::max<int64_t>(merged_max, 1), cM, mM, stream, nullptr);
@@ -2081,6 +2139,7 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
   GfPairIn P;
   P.l_bases = (const uint8_t*)d_l_bases; P.l_quals = (const uint8_t*)d_l_quals; P.l_off = (const int64_t*)d_l_offsets;
   P.r_bases = (const uint8_t*)d_r_bases; P.r_quals = (const uint8_t*)d_r_quals; P.r_off = (const int64_t*)d_r_offsets;
+  P.l_qoff = (const int64_t*)d_l_qoff; P.r_qoff = (const int64_t*)d_r_qoff;
   P.m_bases = mb; P.m_off = m_off; P.m_len = m_len; P.m_diff = m_diff; P.m_rank = m_rank;
   P.cM = cM; P.c1 = c1; P.c2 = c2; P.mM = mM; P.m1 = m1; P.m2 = m2;
   P.gene_reversed = idx->d_gene_rev; P.n_genes = idx->table.n_genes;
@@ -2105,6 +2164,27 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
                      (const int64_t*)(scal + 5), hits_cap, hit_bytes_cap, totals);
   GF_HIP(hipGetLastError());
   return GF_OK;
+}
+
+int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void* d_l_quals, const void* d_l_offsets,
+                         int64_t l_bytes, const void* d_r_bases, const void* d_r_quals, const void* d_r_offsets,
+                         int64_t r_bytes, int64_t n, int32_t max_read_len, int64_t pair_id_base, int64_t retry_cap,
+                         void* d_hits, int64_t hits_cap, void* d_hit_bases, void* d_hit_quals, int64_t hit_bytes_cap,
+                         void* d_totals, void* stream) {
+  return scan_pairs_impl(idx, d_l_bases, d_l_quals, d_l_offsets, l_bytes, d_r_bases, d_r_quals, d_r_offsets, r_bytes, n,
+                         max_read_len, pair_id_base, retry_cap, d_hits, hits_cap, d_hit_bases, d_hit_quals, hit_bytes_cap,
+                         d_totals, stream, nullptr, nullptr);
+}
+
+int gf_scan_pairs_text_device(const gf_index* idx, const void* d_l_bases, const void* d_l_text, const void* d_l_qual_off,
+                              const void* d_l_offsets, int64_t l_bytes, const void* d_r_bases, const void* d_r_text,
+                              const void* d_r_qual_off, const void* d_r_offsets, int64_t r_bytes, int64_t n,
+                              int32_t max_read_len, int64_t pair_id_base, int64_t retry_cap, void* d_hits, int64_t hits_cap,
+                              void* d_hit_bases, void* d_hit_quals, int64_t hit_bytes_cap, void* d_totals, void* stream) {
+  if (n > 0 && (!d_l_qual_off || !d_r_qual_off)) return fail(GF_ERR_ARG, "null quality offsets");
+  return scan_pairs_impl(idx, d_l_bases, d_l_text, d_l_offsets, l_bytes, d_r_bases, d_r_text, d_r_offsets, r_bytes, n,
+                         max_read_len, pair_id_base, retry_cap, d_hits, hits_cap, d_hit_bases, d_hit_quals, hit_bytes_cap,
+                         d_totals, stream, d_l_qual_off, d_r_qual_off);
 }
 
 // ---- streaming host entry: packs submitted ahead of the ones being mapped ---------------------

@@ -31,6 +31,7 @@ class FastqBatch(NamedTuple):
     nl_pos: "object"
     n_newlines: int
     n_bad_quality: int
+    qual_off: "object" = None   # lean cut: quals is the text, and this is where each record's quality line starts
 
     def max_read_len(self) -> int:
         if self.n_records == 0:
@@ -38,8 +39,13 @@ class FastqBatch(NamedTuple):
         return int((self.offsets[1:] - self.offsets[:-1]).max().item())
 
 
-def fastq_cut_device(indexer: Indexer, text, stream=None) -> FastqBatch:
-    """``FastqReader::read`` until it returns None, for a text already in HBM (uint8 tensor)."""
+def fastq_cut_device(indexer: Indexer, text, stream=None, lean: bool = False) -> FastqBatch:
+    """``FastqReader::read`` until it returns None, for a text already in HBM (uint8 tensor).
+
+    ``lean``: the qualities stay in the text (gf_fastq_gather_lean_device) — ``quals`` is then the text itself and
+    ``qual_off`` (int64[n_records]) says where each record's quality line starts; what scan_pairs_device takes as
+    ``l_qual_off`` / ``r_qual_off``.  A text with a quality line of another length than its sequence (the reference
+    does not check; n_bad_quality counts them) is cut the full way instead, and ``qual_off`` is None."""
     import torch
     assert text.dtype == torch.uint8 and text.is_cuda and text.dim() == 1
     dev = text.device
@@ -61,8 +67,16 @@ def fastq_cut_device(indexer: Indexer, text, stream=None) -> FastqBatch:
     n_rec = lines // 4
     offsets = torch.zeros(n_rec + 1, dtype=torch.int64, device=dev)
     bases = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
-    quals = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
     n_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    if lean:
+        qual_off = torch.empty(max(n_rec, 1), dtype=torch.int64, device=dev)
+        _lib.check(L.gf_fastq_gather_lean_device(h, text.data_ptr(), n, nl_pos.data_ptr(), newlines, n_rec,
+                                                 offsets.data_ptr(), bases.data_ptr(), n, qual_off.data_ptr(),
+                                                 n_bad.data_ptr(), ws.data_ptr(), st))
+        total, bad = int(offsets[-1].item()), int(n_bad.item())
+        if bad == 0:
+            return FastqBatch(bases[:total], text, offsets, n_rec, nl_pos[:newlines], newlines, 0, qual_off[:n_rec])
+    quals = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
     _lib.check(L.gf_fastq_gather_device(h, text.data_ptr(), n, nl_pos.data_ptr(), newlines, n_rec, offsets.data_ptr(),
                                         bases.data_ptr(), quals.data_ptr(), n, n_bad.data_ptr(), ws.data_ptr(), st))
     total = int(offsets[-1].item())

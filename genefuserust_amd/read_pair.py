@@ -124,10 +124,14 @@ class PairScan(NamedTuple):
 
 def scan_pairs_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_quals, r_off, max_read_len: int,
                       pair_id_base: int = 0, hits_cap: Optional[int] = None, bytes_cap: Optional[int] = None,
-                      retry_cap: int = 0, stream=None) -> PairScan:
+                      retry_cap: int = 0, stream=None, l_qual_off=None, r_qual_off=None) -> PairScan:
     """``PairEndScanner::scan_pair_end`` (pescanner.rs:427-518) for a pack of pairs resident in HBM,
     one asynchronous call: gf_scan_pairs_device.  No host round trip between merge, the mapping
-    passes, the reverse-complement retries and the compaction of the matched reads."""
+    passes, the reverse-complement retries and the compaction of the matched reads.
+
+    ``l_qual_off`` / ``r_qual_off`` (both or neither): the qualities were left in the FASTQ texts
+    (fastq_cut_device(lean=True)) — ``l_quals`` / ``r_quals`` are the texts and these say where each record's
+    quality line starts (gf_scan_pairs_text_device)."""
     import torch
     n = l_off.numel() - 1
     dev = l_bases.device
@@ -141,6 +145,16 @@ def scan_pairs_device(indexer: Indexer, l_bases, l_quals, l_off, r_bases, r_qual
     hb = torch.empty(max(bytes_cap, 1), dtype=torch.uint8, device=dev)
     hq = torch.empty(max(bytes_cap, 1), dtype=torch.uint8, device=dev)
     totals = torch.zeros(8, dtype=torch.int64, device=dev)
+    assert (l_qual_off is None) == (r_qual_off is None)
+    if l_qual_off is not None:
+        assert l_qual_off.dtype == torch.int64 and r_qual_off.dtype == torch.int64
+        assert l_qual_off.numel() >= n and r_qual_off.numel() >= n
+        _lib.check(_lib.lib().gf_scan_pairs_text_device(
+            indexer._handle(), l_bases.data_ptr(), l_quals.data_ptr(), l_qual_off.data_ptr(), l_off.data_ptr(), l_bases.numel(),
+            r_bases.data_ptr(), r_quals.data_ptr(), r_qual_off.data_ptr(), r_off.data_ptr(), r_bases.numel(), n,
+            int(max_read_len), int(pair_id_base), int(retry_cap), hits.data_ptr(), hits_cap, hb.data_ptr(), hq.data_ptr(),
+            bytes_cap, totals.data_ptr(), st))
+        return PairScan(hits, hb, hq, totals)
     _lib.check(_lib.lib().gf_scan_pairs_device(
         indexer._handle(), l_bases.data_ptr(), l_quals.data_ptr(), l_off.data_ptr(), l_bases.numel(),
         r_bases.data_ptr(), r_quals.data_ptr(), r_off.data_ptr(), r_bases.numel(), n, int(max_read_len),

@@ -118,7 +118,8 @@ def scan_pair_text_stream(indexer: Indexer, r1_text: np.ndarray, r2_text: np.nda
             texts.append(buf[CARRY_MAX - n0:CARRY_MAX + s.chunk_len[slot]])
         # records of both texts (device).  A side whose last byte has arrived counts its unterminated last
         # line (fastq_reader.rs:75-147); the others only the lines that end inside the chunk.
-        batches = [fastq_cut_device(indexer, t) for t in texts]
+        # (lean: the qualities stay in the chunk's text, which lives in the slot's buffer until the scan below is done)
+        batches = [fastq_cut_device(indexer, t, lean=True) for t in texts]
         counts = [b.n_records if f else b.n_newlines // 4 for b, f in zip(batches, final)]
         m = min(counts)
         new_carries = []
@@ -140,13 +141,19 @@ def scan_pair_text_stream(indexer: Indexer, r1_text: np.ndarray, r2_text: np.nda
             l, r = batches
             lo, ro = l.offsets[:m + 1], r.offsets[:m + 1]
             lb, rb_ = int(lo[-1].item()), int(ro[-1].item())
-            res = scan_pairs_device(indexer, l.bases[:lb], l.quals[:lb], lo, r.bases[:rb_], r.quals[:rb_], ro,
-                                    max_read_len, pair_id_base=pairs_done)
+            lean = l.qual_off is not None and r.qual_off is not None
+            if not lean:   # one side has a quality line of another length than its sequence: both the full way
+                l = l if l.qual_off is None else fastq_cut_device(indexer, texts[0])
+                r = r if r.qual_off is None else fastq_cut_device(indexer, texts[1])
+            lq, rq = (l.quals, r.quals) if lean else (l.quals[:lb], r.quals[:rb_])
+            qo = dict(l_qual_off=l.qual_off[:m], r_qual_off=r.qual_off[:m]) if lean else {}
+            res = scan_pairs_device(indexer, l.bases[:lb], lq, lo, r.bases[:rb_], rq, ro,
+                                    max_read_len, pair_id_base=pairs_done, **qo)
             out = res.download()
             if out[3]["overflow"]:
-                res = scan_pairs_device(indexer, l.bases[:lb], l.quals[:lb], lo, r.bases[:rb_], r.quals[:rb_], ro,
+                res = scan_pairs_device(indexer, l.bases[:lb], lq, lo, r.bases[:rb_], rq, ro,
                                         max_read_len, pair_id_base=pairs_done, hits_cap=3 * m,
-                                        bytes_cap=2 * (lb + rb_) + 64, retry_cap=3 * m)
+                                        bytes_cap=2 * (lb + rb_) + 64, retry_cap=3 * m, **qo)
                 out = res.download()
             out[3]["pairs"] = m
         ev = torch.cuda.Event()

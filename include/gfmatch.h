@@ -329,6 +329,12 @@ int gf_fastq_index_device(const gf_index* idx, const void* d_text, int64_t n_byt
 int gf_fastq_gather_device(const gf_index* idx, const void* d_text, int64_t n_bytes, const void* d_nl_pos,
                            int64_t n_newlines, int64_t n_records, void* d_offsets, void* d_bases, void* d_quals,
                            int64_t cap_bytes, void* d_n_bad, void* d_workspace, void* stream);
+/* gf_fastq_gather_lean_device: the sequence lines only; d_qual_off[r] (int64[n_records]) = byte offset of record r's
+ * quality line in the text, for gf_scan_pairs_text_device.  *d_n_bad still counts the records whose quality line
+ * has another length than the sequence: with any of those, gather the full way (the in-place form cannot pad). */
+int gf_fastq_gather_lean_device(const gf_index* idx, const void* d_text, int64_t n_bytes, const void* d_nl_pos,
+                                int64_t n_newlines, int64_t n_records, void* d_offsets, void* d_bases, int64_t cap_bytes,
+                                void* d_qual_off, void* d_n_bad, void* d_workspace, void* stream);
 
 /* --- the pair policy, device resident --------------------
  * PairEndScanner::scan_pair_end (pescanner.rs:427-518) for a pack of n pairs whose records are in
@@ -382,6 +388,16 @@ int gf_scan_pairs_device(const gf_index* idx, const void* d_l_bases, const void*
                          int64_t r_bytes, int64_t n, int32_t max_read_len, int64_t pair_id_base, int64_t retry_cap,
                          void* d_hits, int64_t hits_cap, void* d_hit_bases, void* d_hit_quals, int64_t hit_bytes_cap,
                          void* d_totals, void* stream);
+/* The same with the qualities left in the FASTQ texts (gf_fastq_gather_lean_device): d_l_text / d_r_text are the
+ * texts and d_l_qual_off / d_r_qual_off (int64[n]) where each record's quality line starts.  The pipeline reads
+ * qualities for the mismatching columns of an overlap (read.rs:380-428), for the reads it searches again reversed
+ * and for the hit records — a few bytes per thousand pairs — so copying 1.5 GB of them per 10 M records first
+ * (half of what gf_fastq_gather_device writes) buys nothing.  Same results, record for record. */
+int gf_scan_pairs_text_device(const gf_index* idx, const void* d_l_bases, const void* d_l_text, const void* d_l_qual_off,
+                              const void* d_l_offsets, int64_t l_bytes, const void* d_r_bases, const void* d_r_text,
+                              const void* d_r_qual_off, const void* d_r_offsets, int64_t r_bytes, int64_t n,
+                              int32_t max_read_len, int64_t pair_id_base, int64_t retry_cap, void* d_hits, int64_t hits_cap,
+                              void* d_hit_bases, void* d_hit_quals, int64_t hit_bytes_cap, void* d_totals, void* stream);
 
 /* --- streaming host entry ----------------------------------------------------------------------
  * For a host that produces packs of reads while earlier packs are being mapped (the reference's

@@ -438,3 +438,58 @@ def test_tail_on_the_device_after_a_real_pair_scan(gpu_device):
     got = out[:n].cpu().numpy().view(_lib.READMATCH_DTYPE).reshape(-1)
     assert got.tobytes() == want.tobytes() and (status[:n].cpu().numpy() == st).all()
     ix.close()
+
+
+@pytest.mark.gpu
+def test_qualities_left_in_the_text_give_the_same_scan(gpu_device, oracle):
+    """fastq_cut_device(lean=True) + scan_pairs_device(l_qual_off=..): the qualities never leave the FASTQ text (the
+    pipeline reads them at an overlap's mismatching columns, for reverse-complement retries and for hit records
+    only).  Hit records, their bases AND their qualities equal the full gather's byte for byte — on pairs whose
+    qualities matter: random Phred values, so that the merge rule's >= Q30 / <= Q15 test (read.rs:380-428) decides
+    overlaps both ways and merged qualities differ from either read's."""
+    import torch
+    from genefuserust_amd import Indexer, synth
+    from genefuserust_amd.fastq import fastq_cut_device
+    from genefuserust_amd.read_pair import scan_pairs_device
+    from tools.bench_frontend import make_text
+    dev = torch.device("cuda")
+    genes = synth.make_geneset("IDX-T", scale=0.1)
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    synth.MIXES["JUNC"] = (0.1, 0.4, 0.5)
+    n, L = 80_000, 150
+    pr = synth.make_pairs(genes, n, read_len=L, mix="JUNC", seed=11, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    lq = (torch.randint(0, 42, pr.l_quals.shape, generator=g, device=dev) + 33).to(torch.uint8)
+    rq = (torch.randint(0, 42, pr.r_quals.shape, generator=g, device=dev) + 33).to(torch.uint8)
+    # a few mismatches inside the overlaps, so that the quality rule is actually consulted
+    rb = pr.r_bases.clone()
+    pos = torch.randint(0, rb.numel(), (n // 2,), generator=g, device=dev)
+    rb[pos] = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n // 2,), generator=g, device=dev)]
+    t1 = make_text(pr.l_bases, lq, n, L, 1, dev)
+    t2 = make_text(rb, rq, n, L, 2, dev)
+    full1, full2 = fastq_cut_device(ix, t1), fastq_cut_device(ix, t2)
+    lean1, lean2 = fastq_cut_device(ix, t1, lean=True), fastq_cut_device(ix, t2, lean=True)
+    assert lean1.qual_off is not None and lean2.qual_off is not None and full1.qual_off is None
+    assert torch.equal(lean1.bases, full1.bases) and torch.equal(lean1.offsets, full1.offsets)
+    # qual_off points at the quality lines: the same bytes as the gathered qualities
+    k = 1000
+    qo, off = lean2.qual_off[:k].cpu().numpy(), full2.offsets[:k + 1].cpu().numpy()
+    text2, q2 = t2.cpu().numpy().tobytes(), full2.quals.cpu().numpy().tobytes()
+    assert all(text2[qo[i]:qo[i] + (off[i + 1] - off[i])] == q2[off[i]:off[i + 1]] for i in range(k))
+    caps = dict(hits_cap=n, bytes_cap=n * 2 * L)
+    a = scan_pairs_device(ix, full1.bases, full1.quals, full1.offsets, full2.bases, full2.quals, full2.offsets, L, **caps)
+    b = scan_pairs_device(ix, lean1.bases, lean1.quals, lean1.offsets, lean2.bases, lean2.quals, lean2.offsets, L,
+                          l_qual_off=lean1.qual_off, r_qual_off=lean2.qual_off, **caps)
+    ra, ba, qa, ta = a.download()
+    rb_, bb, qb, tb = b.download()
+    assert ta == tb and ta["overflow"] == 0 and ta["hits"] > 500 and ta["merged_pairs"] > 1000 and ta["retried_reads"] > 0
+    assert ra.tobytes() == rb_.tobytes() and ba == bb and qa == qb
+    # and the merged reads among the hits carry merged qualities (neither read's own)
+    assert any(int(r["source"]) == 0 for r in ra)
+    # a text with a quality line of another length: the lean cut steps back to the full one
+    bad = b"@r\nACGTACGTACGTACGTACGT\n+\nIIII\n"
+    tb_ = torch.from_numpy(np.frombuffer(bad, dtype=np.uint8).copy()).to(dev)
+    fb = fastq_cut_device(ix, tb_, lean=True)
+    assert fb.qual_off is None and fb.n_bad_quality == 1 and fb.quals.cpu().numpy().tobytes() == b"IIII" + b"!" * 16
+    ix.close()

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--check", type=int, default=3000)
     ap.add_argument("--profile-mode", action="store_true", help="the timed stages only (for rocprofv3): no host tail, no oracle")
+    ap.add_argument("--full-gather", action="store_true",
+                    help="copy the qualities out of the text too (gf_fastq_gather_device + gf_scan_pairs_device), as before r03 b")
     a = ap.parse_args()
     from genefuserust_amd import FusionMapper, Indexer, synth
     from genefuserust_amd.fastq import fastq_cut_device
@@ -44,10 +46,12 @@ def main():
     kinds = pr.kinds
     del pr
     torch.cuda.synchronize()
-    ms_cut1, b1 = timed(lambda: fastq_cut_device(ix, t1), a.steps, a.warmup)
-    ms_cut2, b2 = timed(lambda: fastq_cut_device(ix, t2), a.steps, a.warmup)
-    assert b1.n_records == b2.n_records == n
-    ms_scan, res = timed(lambda: scan_pairs_device(ix, b1.bases, b1.quals, b1.offsets, b2.bases, b2.quals, b2.offsets, L),
+    lean = not a.full_gather   # the qualities stay in the text (gf_fastq_gather_lean_device, gf_scan_pairs_text_device)
+    ms_cut1, b1 = timed(lambda: fastq_cut_device(ix, t1, lean=lean), a.steps, a.warmup)
+    ms_cut2, b2 = timed(lambda: fastq_cut_device(ix, t2, lean=lean), a.steps, a.warmup)
+    assert b1.n_records == b2.n_records == n and (b1.qual_off is not None) == lean
+    ms_scan, res = timed(lambda: scan_pairs_device(ix, b1.bases, b1.quals, b1.offsets, b2.bases, b2.quals, b2.offsets, L,
+                                                   l_qual_off=b1.qual_off, r_qual_off=b2.qual_off),
                          a.steps, a.warmup)
     ms_tail_dev, tail_dev = timed(lambda: finish_pair_hits_device(ix, res), a.steps, a.warmup)
     rec, hb, hq, tot = res.download()
@@ -86,7 +90,13 @@ def main():
 
     def rows(t, off):
         return [t[int(off[i]):int(off[i + 1])].cpu().numpy().tobytes() for i in ids]
-    L1b, L1q, L2b, L2q = rows(b1.bases, o1), rows(b1.quals, o1), rows(b2.bases, o2), rows(b2.quals, o2)
+
+    def qrows(b, off):   # the qualities of the sampled records: gathered, or still in the text (lean cut)
+        if b.qual_off is None:
+            return rows(b.quals, off)
+        qo = b.qual_off.cpu().numpy()
+        return [b.quals[int(qo[i]):int(qo[i]) + int(off[i + 1] - off[i])].cpu().numpy().tobytes() for i in ids]
+    L1b, L1q, L2b, L2q = rows(b1.bases, o1), qrows(b1, o1), rows(b2.bases, o2), qrows(b2, o2)
     pairs = list(zip(L1b, L1q, L2b, L2q))
     want, _ = _reference_policy(oracle_py, ox, genes.reversed_flags, pairs)
     flat = [(ids[p], w) for p, ws in enumerate(want) for w in ws]
@@ -108,8 +118,11 @@ def main():
         ft = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "frontend_traffic.json")))
         scale = n / ft["pairs"]
         rec_bytes = int(t1.numel()) // n
-        algo = {"fastq_cut": rec_bytes * n + 2 * L * n + 8 * (n + 1),
-                "scan_pairs_device": 2 * (2 * L * n + 8 * (n + 1)) + 64 * int(tot["hits"]) + 2 * int(tot["hit_bytes"])}
+        # (lean: a cut writes no qualities but one quality offset per record; the scan reads no qualities to speak of)
+        algo = {"fastq_cut": rec_bytes * n + (L * n + 8 * n if lean else 2 * L * n) + 8 * (n + 1),
+                "scan_pairs_device": 2 * ((L if lean else 2 * L) * n + 8 * (n + 1)) + 64 * int(tot["hits"]) + 2 * int(tot["hit_bytes"])}
+        if bool(ft.get("lean")) != lean:
+            raise ValueError("profiles/frontend_traffic.json was measured %s the qualities' copy" % ("without" if ft.get("lean") else "with"))
         for st, ms in (("fastq_cut", 0.5 * (ms_cut1 + ms_cut2)), ("scan_pairs_device", ms_scan)):
             e = ft["stages"][st]
             b = (e["read_bytes"] + e["write_bytes"]) * scale
@@ -125,6 +138,8 @@ def main():
         "value": n / (total / 1e3), "unit": "pairs/s", "pairs": n, "read_len": L, "index_shape": a.shape,
         "stage_ms": {"fastq_cut_R1": round(ms_cut1, 3), "fastq_cut_R2": round(ms_cut2, 3), "scan_pairs_device": round(ms_scan, 3)},
         "scan_pairs_only_pairs_per_s": n / (ms_scan / 1e3),
+        "qualities": ("left in the text: gf_fastq_gather_lean_device + gf_scan_pairs_text_device" if lean else
+                      "copied out of the text: gf_fastq_gather_device + gf_scan_pairs_device"),
         "roofline": roof,
         "totals": tot, "junction_pairs": int((kinds == 2).sum()),
         "host_tail": {"hits": len(done), "seconds": round(tail_s, 4), "hits_per_s": len(done) / tail_s if tail_s else None,

@@ -58,11 +58,12 @@ def main():
         elif name.startswith("gf_k_merge_find"):
             cur = {"stage": "scan_pairs_device", "k": []}
             stages.append(cur)
-        elif name.startswith(("gf_k_index_", "gf_k_classify", "gf_k_sort_dupes")):
-            cur = None
+        elif name.startswith(("gf_k_index_", "gf_k_classify", "gf_k_sort_dupes", "gf_k_filter_", "gf_k_upper_", "gf_k_pair_hits_finish")):
+            cur = None   # (the index build; the device tail, which bench_pairs.py times as a stage of its own)
         if cur is not None:
             cur["k"].append(i)
-    res = {"pairs": pairs, "stages": {}, "source_dir": os.path.basename(out)}
+    # (bench_pairs.py leaves the qualities in the text unless --full-gather: tools/profile_pairs.sh runs it plainly)
+    res = {"pairs": pairs, "stages": {}, "source_dir": os.path.basename(out), "lean": True}
     for st in ("fastq_cut", "scan_pairs_device"):
         inv = [s for s in stages if s["stage"] == st]
         if not inv:
