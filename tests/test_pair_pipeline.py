@@ -493,3 +493,56 @@ def test_qualities_left_in_the_text_give_the_same_scan(gpu_device, oracle):
     fb = fastq_cut_device(ix, tb_, lean=True)
     assert fb.qual_off is None and fb.n_bad_quality == 1 and fb.quals.cpu().numpy().tobytes() == b"IIII" + b"!" * 16
     ix.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_len", [150, 250, 300])
+def test_qualities_in_the_text_with_ragged_reads(gpu_device, max_len):
+    """The lean path again on texts written record by record: reads of 40 .. max_len bases (the 10-word, the 16-word
+    and the byte-loop merge search, by max_len), qualities of their own per base, overlapping fragments with planted
+    mismatches, a last record without its newline — against the full gather + gf_scan_pairs_device."""
+    import torch
+    from genefuserust_amd import Indexer
+    from genefuserust_amd.fastq import fastq_cut_device
+    from genefuserust_amd.read_pair import scan_pairs_device
+    g = json.load(open(GOLDEN))
+    genes = [None if x is None else x.encode() for x in g["genes"]]
+    ix = Indexer.from_gene_slices(genes, g["reversed"])
+    ix.make_index()
+    rng = np.random.default_rng(1000 + max_len)
+    g0, g1 = genes[0], genes[1]
+    t1, t2 = [], []
+    n = 1500
+    for k in range(n):
+        if k % 3 != 2:
+            p, q = int(rng.integers(400, len(g0) - 400)), int(rng.integers(400, len(g1) - 500))
+            frag = g0[p - 300:p] + g1[q:q + 300]
+        else:
+            frag = rand_seq(rng, 600)
+        lo = int(rng.integers(0, 100))
+        flen = int(rng.integers(60, 2 * max_len))
+        f = bytearray(frag[lo:lo + flen])
+        l1, l2 = int(rng.integers(40, max_len + 1)), int(rng.integers(40, max_len + 1))
+        r1 = bytes(f[:l1])
+        r2 = bytearray(rc(bytes(f))[:l2])
+        for _ in range(int(rng.integers(0, 3))):          # mismatches between the mates
+            r2[int(rng.integers(0, len(r2)))] = ord("ACGT"[int(rng.integers(0, 4))])
+        q1 = bytes(rng.integers(33, 75, size=len(r1), dtype=np.uint8))
+        q2 = bytes(rng.integers(33, 75, size=len(r2), dtype=np.uint8))
+        t1.append(b"@p%d/1\n" % k + r1 + b"\n+\n" + q1 + b"\n")
+        t2.append(b"@p%d/2\n" % k + bytes(r2) + b"\n+\n" + q2 + b"\n")
+    text1, text2 = b"".join(t1)[:-1], b"".join(t2)      # (R1's last line ends with the file)
+    d1 = torch.from_numpy(np.frombuffer(text1, dtype=np.uint8).copy()).cuda()
+    d2 = torch.from_numpy(np.frombuffer(text2, dtype=np.uint8).copy()).cuda()
+    f1, f2 = fastq_cut_device(ix, d1), fastq_cut_device(ix, d2)
+    l1_, l2_ = fastq_cut_device(ix, d1, lean=True), fastq_cut_device(ix, d2, lean=True)
+    assert f1.n_records == f2.n_records == l1_.n_records == n and l1_.qual_off is not None
+    caps = dict(hits_cap=3 * n, bytes_cap=3 * n * 2 * max_len)
+    a = scan_pairs_device(ix, f1.bases, f1.quals, f1.offsets, f2.bases, f2.quals, f2.offsets, max_len, **caps)
+    b = scan_pairs_device(ix, l1_.bases, l1_.quals, l1_.offsets, l2_.bases, l2_.quals, l2_.offsets, max_len,
+                          l_qual_off=l1_.qual_off, r_qual_off=l2_.qual_off, **caps)
+    ra, ba, qa, ta = a.download()
+    rb_, bb, qb, tb = b.download()
+    assert ta == tb and ta["overflow"] == 0 and ta["hits"] >= 10 and ta["merged_pairs"] > 100 and ta["retried_reads"] >= 0
+    assert ra.tobytes() == rb_.tobytes() and ba == bb and qa == qb
+    ix.close()
