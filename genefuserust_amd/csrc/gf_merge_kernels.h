@@ -578,6 +578,69 @@ __device__ __forceinline__ void gf_mwb_piece(const uint8_t* __restrict__ s1, con
   }
 }
 
+// The loads of a piece (gf_mwb_piece's first half), so that a thread can have several pieces' loads in flight
+// before it looks at any of them.
+struct GfMwbLoad {
+  GfBytes8 a, t;
+  int under;
+};
+__device__ __forceinline__ GfMwbLoad gf_mwb_fetch(const uint8_t* __restrict__ s1, int len1, const uint8_t* __restrict__ s2,
+                                                   int len2, int offset, int k) {
+  GfMwbLoad L;
+  L.a = *(const GfBytes8*)(s1 + (k < len1 ? k : 0));  // (not used at all when k >= len1)
+  int jl = len2 - 1 - (k + 7 - offset);               // R2 index of output byte k+7
+  L.under = jl < 0 ? -jl : 0;                         // > 0 only in the read's last piece
+  if (k + 8 <= offset) jl = 0;  // a piece of R1 alone: rc(R2) is not looked at (and jl would lie past R2's end)
+  L.t = *(const GfBytes8*)(s2 + (jl < 0 ? 0 : jl));
+  return L;
+}
+// ... and the rest of gf_mwb_piece on the bytes fetched
+__device__ __forceinline__ void gf_mwb_finish(const GfMwbLoad& L, const uint8_t* __restrict__ q1, int len1,
+                                              const uint8_t* __restrict__ q2, int len2, int mlen, int offset, int k,
+                                              uint8_t* __restrict__ os) {
+  uint64_t t64 = (uint64_t)L.t.v[0] | ((uint64_t)L.t.v[1] << 32);
+  t64 <<= 8 * L.under;
+  uint32_t o0 = gf_rc4((uint32_t)(t64 >> 32)), o1 = gf_rc4((uint32_t)t64);  // rc(R2) bytes for k..k+3, k+4..k+7
+  const int n1 = offset - k;  // number of leading bytes that are R1's
+  if (n1 > 0) {
+    const uint32_t m0 = n1 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * n1)) - 1u);
+    const uint32_t m1 = n1 >= 8 ? 0xFFFFFFFFu : (n1 <= 4 ? 0u : ((1u << (8 * (n1 - 4))) - 1u));
+    o0 = (L.a.v[0] & m0) | (o0 & ~m0);
+    o1 = (L.a.v[1] & m1) | (o1 & ~m1);
+  }
+  // inside the overlap (offset <= pos < len1) a column where the reads disagree is R1's when R1 is sure and R2 is not
+  if (k < len1 && k + 8 > offset) {
+    const uint32_t x0 = L.a.v[0] ^ o0, x1 = L.a.v[1] ^ o1;
+    if (x0 | x1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pos = k + i;
+        const uint32_t xb = ((i < 4 ? x0 : x1) >> (8 * (i & 3))) & 0xFFu;
+        if (xb && pos >= offset && pos < len1 && pos < mlen) {
+          if (q1[pos] >= '?' && q2[len2 - 1 - (pos - offset)] <= '0') {
+            const uint32_t b1 = ((i < 4 ? L.a.v[0] : L.a.v[1]) >> (8 * (i & 3))) & 0xFFu;
+            if (i < 4) o0 = (o0 & ~(0xFFu << (8 * (i & 3)))) | (b1 << (8 * (i & 3)));
+            else o1 = (o1 & ~(0xFFu << (8 * (i & 3)))) | (b1 << (8 * (i & 3)));
+          }
+        }
+      }
+    }
+  }
+  if (k + 8 <= mlen) {
+    GfBytes8 o;
+    o.v[0] = o0;
+    o.v[1] = o1;
+    *(GfBytes8*)(os + k) = o;
+  } else {
+    const uint64_t o64 = (uint64_t)o0 | ((uint64_t)o1 << 32);
+    for (int i = 0; k + i < mlen; ++i) os[k + i] = (uint8_t)(o64 >> (8 * i));
+  }
+}
+
+// r03 b: the merged reads of a round of 256 pairs as ONE list of 8-byte pieces — a thread takes pieces t, t + 256, ..
+// of the round, whatever reads they belong to, four of them in flight at a time.  (Two reads per wavefront, a piece per
+// lane: 34 of 64 lanes had a piece of a 270-base read and one round trip's worth of loads in flight; 0.82 ms per 10 M
+// pairs, its waves waiting 54 % of their cycles.)
 __global__ __launch_bounds__(256) void gf_k_merge_write_bases(const uint8_t* __restrict__ l_bases,
                                                               const uint8_t* __restrict__ l_quals,
                                                               const int64_t* __restrict__ l_off,
@@ -588,44 +651,57 @@ __global__ __launch_bounds__(256) void gf_k_merge_write_bases(const uint8_t* __r
                                                               const int32_t* __restrict__ in_len,
                                                               const int64_t* __restrict__ out_pos,
                                                               uint8_t* __restrict__ out_bases) {
-  __shared__ unsigned int s_cnt;
+  __shared__ int s_wave[4];
+  __shared__ int s_first[257];  // the pair's first piece in the round's list (pairs that did not merge: none)
   __shared__ int64_t s_l[256], s_r[256], s_dst[256], s_lq[256], s_rq[256];
   __shared__ int s_len1[256], s_len2[256], s_mlen[256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
   for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
-    __syncthreads();
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    const int64_t p0 = base + threadIdx.x;
+    __syncthreads();  // (the previous round's readers are done with the arrays)
+    const int64_t p0 = base + tid;
     const int ml = p0 < n ? in_len[p0] : 0;
-    const bool merged = ml > 0;
-    const unsigned int slot = gf_wave_append_lds(merged, &s_cnt);
-    if (merged) {
+    if (ml > 0) {
       const int64_t lo = l_off[p0], ro = r_off[p0];
-      s_l[slot] = lo;
-      s_r[slot] = ro;
-      s_lq[slot] = l_qoff ? l_qoff[p0] : lo;
-      s_rq[slot] = r_qoff ? r_qoff[p0] : ro;
-      s_len1[slot] = (int)(l_off[p0 + 1] - lo);
-      s_len2[slot] = (int)(r_off[p0 + 1] - ro);
-      s_mlen[slot] = ml;
-      s_dst[slot] = out_pos[p0];
+      s_l[tid] = lo;
+      s_r[tid] = ro;
+      s_lq[tid] = l_qoff ? l_qoff[p0] : lo;
+      s_rq[tid] = r_qoff ? r_qoff[p0] : ro;
+      s_len1[tid] = (int)(l_off[p0 + 1] - lo);
+      s_len2[tid] = (int)(r_off[p0 + 1] - ro);
+      s_mlen[tid] = ml;
+      s_dst[tid] = out_pos[p0];
     }
+    int total;
+    const int first = gf_block_exclusive_scan(ml > 0 ? (ml + 7) >> 3 : 0, s_wave, &total);
+    s_first[tid] = first;
+    if (tid == 0) s_first[256] = total;
     __syncthreads();
-    const unsigned int cnt = s_cnt;
-    for (unsigned int e0 = 2 * wave; e0 < cnt; e0 += 8) {
-      const unsigned int e1 = e0 + 1;
-      const bool two = e1 < cnt;
-      const unsigned int ex = two ? e1 : e0;
-      const int len1a = s_len1[e0], len2a = s_len2[e0], mla = s_mlen[e0];
-      const int len1b = s_len1[ex], len2b = s_len2[ex], mlb = two ? s_mlen[ex] : 0;
-      const int mmax = mla > mlb ? mla : mlb;
-      for (int k0 = 0; k0 < mmax; k0 += 512) {
-        gf_mwb_piece(l_bases + s_l[e0], l_quals + s_lq[e0], len1a, r_bases + s_r[e0], r_quals + s_rq[e0], len2a, mla,
-                     mla - len2a, k0 + 8 * lane, out_bases + s_dst[e0]);
-        gf_mwb_piece(l_bases + s_l[ex], l_quals + s_lq[ex], len1b, r_bases + s_r[ex], r_quals + s_rq[ex], len2b, mlb,
-                     mlb - len2b, k0 + 8 * lane, out_bases + s_dst[ex]);
+    for (int q0 = tid; q0 < total; q0 += 4 * 256) {
+      GfMwbLoad L[4];
+      int e[4], kk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + 256 * u;
+        e[u] = -1;
+        if (q < total) {
+          int i = 0, j = 256;  // the pair whose pieces hold q: the largest i with s_first[i] <= q
+          while (j - i > 1) {
+            const int mid = (i + j) >> 1;
+            if (s_first[mid] <= q) i = mid; else j = mid;
+          }
+          e[u] = i;
+          kk[u] = 8 * (q - s_first[i]);
+          L[u] = gf_mwb_fetch(l_bases + s_l[i], s_len1[i], r_bases + s_r[i], s_len2[i], s_mlen[i] - s_len2[i], kk[u]);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);  // the four pieces' loads before anybody's stores
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e[u] >= 0) {
+          const int i = e[u];
+          gf_mwb_finish(L[u], l_quals + s_lq[i], s_len1[i], r_quals + s_rq[i], s_len2[i], s_mlen[i], s_mlen[i] - s_len2[i],
+                        kk[u], out_bases + s_dst[i]);
+        }
     }
   }
 }
