@@ -341,7 +341,7 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_pair_retry_write(
 // overflow flag.  totals: [0] hits, [1] hit bytes, [2] merged pairs, [3] retried reads, [4] overflow bits
 __global__ void gf_k_pair_retry_tail(const int64_t* __restrict__ d_n_retry, const int64_t* __restrict__ d_retry_bytes,
                                      int64_t cap_reads, int64_t cap_bytes, int64_t* __restrict__ r_off,
-                                     int64_t* __restrict__ totals) {
+                                     int64_t* __restrict__ totals, unsigned int* __restrict__ n_exact) {
   const int64_t nr = *d_n_retry, nb = *d_retry_bytes;
   // Over capacity: the whole retry batch is emptied (every offset 0) and the flag raised — the caller
   // runs the pack again with room for all (gf_scan_pairs_device: totals[4]); a partly searched batch
@@ -354,6 +354,7 @@ __global__ void gf_k_pair_retry_tail(const int64_t* __restrict__ d_n_retry, cons
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     totals[3] = nr;
     if (over) totals[4] |= 1;
+    *n_exact = over ? 0u : (unsigned int)nr;  // the reads the retry pass maps (it takes them one wavefront each)
   }
 }
 

@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(WAVES * 64, LCAP <= 256 ? 8 : (LCAP <= 1024 ? 3 : 1
   GfMapSmem<LCAP>& S = smem[wib];
   const unsigned int nl = *n_list;
   for (unsigned int k = blockIdx.x * WAVES + wib; k < nl; k += gridDim.x * WAVES) {
-    const int64_t r = (int64_t)list[(int64_t)k * stride];
+    const int64_t r = list ? (int64_t)list[(int64_t)k * stride] : (int64_t)k;  // (no list: reads 0 .. *n_list - 1)
     const int64_t off0 = T.fixed_len ? r * (int64_t)T.fixed_len : offsets[r];
     const int L = T.fixed_len ? T.fixed_len : (int)(offsets[r + 1] - off0);
     gf_wave_lds_sync();

@@ -2148,10 +2148,36 @@ static int scan_pairs_impl(const gf_index* idx, const void* d_l_bases, const voi
   hipLaunchKernelGGL(gf_k_pair_retry_write, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, (const uint8_t*)stt,
                      (const int64_t*)toA, (const int64_t*)toB, retry_cap, retry_bytes_cap, r_off, rb, rq, slot_of);
   hipLaunchKernelGGL(gf_k_pair_retry_tail, dim3((unsigned)std::min<int64_t>((retry_cap + 256) / 256, 1024)), dim3(256), 0, st,
-                     (const int64_t*)(scal + 1), (const int64_t*)(scal + 2), retry_cap, retry_bytes_cap, r_off, totals);
+                     (const int64_t*)(scal + 1), (const int64_t*)(scal + 2), retry_cap, retry_bytes_cap, r_off, totals,
+                     (unsigned int*)(scal + 6));
   GF_HIP(hipGetLastError());
-  rc = map_reads_device_impl(idx, rb, r_off, retry_cap, (int32_t)std::max<int64_t>(merged_max, 1), cR, mR, stream, nullptr);
-  if (rc != GF_OK) return rc;
+  // The retries — a few per ten thousand pairs, every one a read that does map — go straight to the exact
+  // wave-per-read kernel, as many as there are (the count is on the device).  Through the flat pipeline like the other
+  // passes (GF_RETRY_FLAT=1) they cost 0.41 ms per 10 M pairs: launches over retry_cap mostly empty slots, and a
+  // bucket kernel whose every lane walks a junction read's thirty windows one probe after the other.
+  static const bool retry_flat = getenv("GF_RETRY_FLAT") != nullptr;
+  if (retry_flat) {
+    rc = map_reads_device_impl(idx, rb, r_off, retry_cap, (int32_t)std::max<int64_t>(merged_max, 1), cR, mR, stream, nullptr);
+    if (rc != GF_OK) return rc;
+  } else {
+    GfTable T = idx->table;
+    T.skip = nullptr;
+    T.fixed_len = 0;
+    const unsigned int* n_exact = (const unsigned int*)(scal + 6);
+    if (merged_max <= 256)
+      hipLaunchKernelGGL((gf_k_map_reads_list<256, 4, false>), dim3(idx->n_cus * 8), dim3(256), 0, st, T, (const uint8_t*)rb,
+                         (const uint32_t*)nullptr, (const uint16_t*)nullptr, (const int64_t*)r_off, (const uint32_t*)nullptr,
+                         (int64_t)1, n_exact, cR, mR);
+    else if (merged_max <= 1024)
+      hipLaunchKernelGGL((gf_k_map_reads_list<1024, 4, false>), dim3(idx->n_cus * 3), dim3(256), 0, st, T, (const uint8_t*)rb,
+                         (const uint32_t*)nullptr, (const uint16_t*)nullptr, (const int64_t*)r_off, (const uint32_t*)nullptr,
+                         (int64_t)1, n_exact, cR, mR);
+    else
+      hipLaunchKernelGGL((gf_k_map_reads_list<4096, 2, false>), dim3(idx->n_cus * 4), dim3(128), 0, st, T, (const uint8_t*)rb,
+                         (const uint32_t*)nullptr, (const uint16_t*)nullptr, (const int64_t*)r_off, (const uint32_t*)nullptr,
+                         (int64_t)1, n_exact, cR, mR);
+    GF_HIP(hipGetLastError());
+  }
   // 4. the matches, in push order, with their reads
   hipLaunchKernelGGL(gf_k_pair_final_count, dim3((unsigned)ntiles), dim3(GF_CTHREADS), 0, st, P, n, (const uint8_t*)stt,
                      (const int32_t*)slot_of, (const uint8_t*)cR, (const gf_seqmatch*)mR, tcA, tcB);
