@@ -990,7 +990,7 @@ static int segment_mask_test_impl(const gf_index* idx, const uint8_t* masks, con
 
 static int map_span_device(const gf_index* idx, const ReadSrc& src, const int64_t* offsets, int64_t n,
                            int32_t max_read_len, uint8_t* counts, gf_seqmatch* matches, hipStream_t st, bool prof,
-                           const int32_t* skip, int32_t fixed_len = 0) {
+                           const int32_t* skip, int32_t fixed_len = 0, const int64_t* n_dev = nullptr) {
   gf_index* mix = const_cast<gf_index*>(idx);
   const uint8_t* bases = src.bases;
   if (src.packed() && idx->map_variant != 0)
@@ -998,6 +998,7 @@ static int map_span_device(const gf_index* idx, const ReadSrc& src, const int64_
   GfTable T = idx->table;
   T.skip = skip;  // (per call: the index itself stays read-only)
   T.fixed_len = fixed_len;
+  T.n_dev = n_dev;
   if (fixed_len > 0 && (idx->map_variant != 0 || fixed_len > 320))
     return fail(GF_ERR_ARG, "fixed-length batches are taken by the flat pipeline only (reads of up to 320 bases, gf_set_map_variant 0)");
   // persistent grid: enough waves to fill every CU, reads interleaved across waves
@@ -1073,7 +1074,7 @@ static int64_t span_max_reads() {
 static int map_reads_device_impl(const gf_index* idx, const void* d_bases, const void* d_offsets, int64_t n,
                                  int32_t max_read_len, void* d_counts, void* d_matches, void* stream,
                                  const int32_t* d_skip, const void* d_pk = nullptr, const void* d_iv = nullptr,
-                                 int32_t fixed_len = 0) {
+                                 int32_t fixed_len = 0, const int64_t* d_n_actual = nullptr) {
   if (!idx || n < 0) return fail(GF_ERR_ARG, "null index or negative n");
   if (n == 0) return GF_OK;
   if ((!d_offsets && fixed_len <= 0) || !d_counts || !d_matches) return fail(GF_ERR_ARG, "null device pointer");
@@ -1109,7 +1110,8 @@ static int map_reads_device_impl(const gf_index* idx, const void* d_bases, const
       if (span_src.packed() && ((s0 * (int64_t)fixed_len) & 15)) return fail(GF_ERR_ARG, "packed fixed-length batch beyond one span");
     }
     const int rc = map_span_device(idx, span_src, fixed_len > 0 ? nullptr : offsets + s0, ns, max_read_len, counts + s0,
-                                   matches + 2 * s0, st, prof, d_skip ? d_skip + s0 : nullptr, fixed_len);
+                                   matches + 2 * s0, st, prof, d_skip ? d_skip + s0 : nullptr, fixed_len,
+                                   n <= span ? d_n_actual : nullptr);  // (the count is of the whole batch: one span)
     if (rc != GF_OK) return rc;
   }
   if (prof) {
@@ -2129,7 +2131,8 @@ static int scan_pairs_impl(const gf_index* idx, const void* d_l_bases, const voi
                         mb, nullptr, stream, d_l_qoff, d_r_qoff);
   if (rc != GF_OK) return rc;
   // 2. the merged reads; R1 and R2 of the pairs that did not merge (in place, the others skipped)
-  rc = map_reads_device_impl(idx, mb, c_off, n, (int32_t)std::max<int64_t>(merged_max, 1), cM, mM, stream, nullptr);
+  rc = map_reads_device_impl(idx, mb, c_off, n, (int32_t)std::max<int64_t>(merged_max, 1), cM, mM, stream, nullptr, nullptr,
+                             nullptr, 0, (const int64_t*)(scal + 5));  // (the merged reads are the first scal[5] of the n slots)
   if (rc != GF_OK) return rc;
   rc = map_reads_device_impl(idx, d_l_bases, d_l_offsets, n, std::max(max_read_len, 1), c1, m1, stream, m_len);
   if (rc != GF_OK) return rc;
@@ -2163,6 +2166,7 @@ static int scan_pairs_impl(const gf_index* idx, const void* d_l_bases, const voi
     GfTable T = idx->table;
     T.skip = nullptr;
     T.fixed_len = 0;
+    T.n_dev = nullptr;
     const unsigned int* n_exact = (const unsigned int*)(scal + 6);
     if (merged_max <= 256)
       hipLaunchKernelGGL((gf_k_map_reads_list<256, 4, false>), dim3(idx->n_cus * 8), dim3(256), 0, st, T, (const uint8_t*)rb,
