@@ -35,14 +35,31 @@ __device__ __forceinline__ int gf_block_exclusive_scan(int v, int* s_wave, int* 
   return base + x - v;
 }
 
+// the thread's GF_CPER (= 16) counts: one 16-byte load where the address allows it (sixteen byte loads took most of
+// the two sweeps' 24 + 30 us per 20 M reads), bytes beyond n read as 0
+__device__ __forceinline__ void gf_counts16(const uint8_t* __restrict__ counts, int64_t r0, int64_t n, uint8_t (&c)[GF_CPER]) {
+  static_assert(GF_CPER == 16, "one uint4 per thread");
+  if (r0 + GF_CPER <= n && (((uintptr_t)(counts + r0)) & 15u) == 0) {
+    const uint4 q = *(const uint4*)(counts + r0);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < GF_CPER; ++k) c[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+  } else {
+#pragma unroll
+    for (int k = 0; k < GF_CPER; ++k) c[k] = r0 + k < n ? counts[r0 + k] : (uint8_t)0;
+  }
+}
+
 __global__ __launch_bounds__(GF_CTHREADS) void gf_k_compact_count(const uint8_t* __restrict__ counts,
                                                                   int64_t n,
                                                                   uint32_t* __restrict__ tile_counts) {
   __shared__ int s_wave[4];
   const int64_t r0 = (int64_t)blockIdx.x * GF_CTILE + (int64_t)threadIdx.x * GF_CPER;
+  uint8_t cv[GF_CPER];
+  gf_counts16(counts, r0, n, cv);
   int c = 0;
-  for (int k = 0; k < GF_CPER; ++k)
-    if (r0 + k < n) c += gf_is_hit(counts[r0 + k]);
+#pragma unroll
+  for (int k = 0; k < GF_CPER; ++k) c += gf_is_hit(cv[k]);
   int total;
   gf_block_exclusive_scan(c, s_wave, &total);
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = (uint32_t)total;
@@ -163,16 +180,18 @@ __global__ __launch_bounds__(GF_CTHREADS) void gf_k_compact_write(
     int64_t cap) {
   __shared__ int s_wave[4];
   const int64_t r0 = (int64_t)blockIdx.x * GF_CTILE + (int64_t)threadIdx.x * GF_CPER;
+  uint8_t cv[GF_CPER];
+  gf_counts16(counts, r0, n, cv);
   int c = 0;
-  for (int k = 0; k < GF_CPER; ++k)
-    if (r0 + k < n) c += gf_is_hit(counts[r0 + k]);
+#pragma unroll
+  for (int k = 0; k < GF_CPER; ++k) c += gf_is_hit(cv[k]);
   int total;
   int64_t pos = tile_offsets[blockIdx.x] + gf_block_exclusive_scan(c, s_wave, &total);
   if (!c) return;
+#pragma unroll
   for (int k = 0; k < GF_CPER; ++k) {
     const int64_t r = r0 + k;
-    if (r >= n) break;
-    const uint8_t cn = counts[r];
+    const uint8_t cn = cv[k];  // (0 beyond n)
     if (!gf_is_hit(cn)) continue;
     if (pos < cap) {
       gf_hit h;
