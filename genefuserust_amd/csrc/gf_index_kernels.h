@@ -778,14 +778,21 @@ __global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uin
     // per block and round (28 K of them on a cancer-sized table) was most of this kernel's 0.41 ms.  A block takes
     // GF_DUPE_GRANULE entries at a time and hands them out itself; what is left of a granule that the next round
     // does not fit in stays empty (the host sizes dupes[] for it).
+    // (A round that needs a quarter of a granule or more and does not fit in what the block holds takes exactly its
+    //  own room and leaves the block's granule alone: a gene set of nothing but 2..5-fold keys — the same genes
+    //  listed twice — then wastes nothing, and the small rounds of an ordinary one at most a quarter of a granule each.)
     if (threadIdx.x == 0 && total) {
-      if (s_pool + total > s_pool_end) {
-        const unsigned long long grab = total > GF_DUPE_GRANULE ? total : GF_DUPE_GRANULE;
-        s_pool = atomicAdd(stats + 6, grab);
-        s_pool_end = s_pool + grab;
+      if (s_pool + total <= s_pool_end) {
+        s_base = s_pool;
+        s_pool += total;
+      } else if (total >= GF_DUPE_GRANULE / 4) {
+        s_base = atomicAdd(stats + 6, (unsigned long long)total);
+      } else {
+        s_pool = atomicAdd(stats + 6, GF_DUPE_GRANULE);
+        s_pool_end = s_pool + GF_DUPE_GRANULE;
+        s_base = s_pool;
+        s_pool += total;
       }
-      s_base = s_pool;
-      s_pool += total;
     }
     __syncthreads();
     uint32_t start = (uint32_t)(total ? s_base : 0ull) + before + incl - mine;

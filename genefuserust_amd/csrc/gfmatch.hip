@@ -787,7 +787,8 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   // the duplicate lists are sized before their keys are counted: every site could be in one (the block comes
   // from the cache of freed indexes in multi-CSV mode); the sweep that assigns them counts the keys on its way
   // (+ a granule per block of the sweep that hands the lists out: gf_k_classify_assign)
-  const uint64_t dupes_cap = std::max<uint64_t>(std::min<uint64_t>(site_bound + (uint64_t)sweep_grid * GF_DUPE_GRANULE,
+  // (granules: a third over what the small rounds really need at worst, and one unfinished granule per block)
+  const uint64_t dupes_cap = std::max<uint64_t>(std::min<uint64_t>(site_bound + site_bound / 2 + (uint64_t)sweep_grid * GF_DUPE_GRANULE,
                                                                    (uint64_t)GF_DUPE_START_MASK + 1), 1);
   GF_HIP(block_alloc(dev, (void**)&ix->d_dupes, dupes_cap * sizeof(uint32_t)));
   struct SideBlock { int dev; GfSideEntry* p = nullptr; ~SideBlock() { if (p) { (void)hipDeviceSynchronize(); block_free(dev, p); } } } d_side{dev};

@@ -219,6 +219,48 @@ def test_filter_partition_overflow_goes_through_the_atomic(gpu_device):
         ix.close()
 
 
+@pytest.mark.parametrize("copies", [2, 5, 6])
+def test_a_gene_list_with_every_gene_repeated(gpu_device, copies):
+    """The same genes listed 2, 5 and 6 times: every key is 2-fold / 5-fold (every site in a duplicate list — the room
+    for the lists is handed out by granules, and here nothing may go to waste: all of dupes[] is spoken for) or 6-fold
+    (all HIGH, no list at all).  Strands, flags, filter, statistics and the lists themselves against the host rebuild."""
+    from genefuserust_amd import Indexer
+    rng = np.random.default_rng(77 + copies)
+    base = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)) for n in (30000, 17000, 9000)]
+    genes = base * copies
+    ix = Indexer.from_gene_slices(genes)
+    ix.make_index()
+    try:
+        gdu, filt, lin_base = _export(ix, 0), _export(ix, 1), _export(ix, 2)
+        even, flags, want_filter, sites = _expected(genes, lin_base, gdu.shape[0] // 2, filt.shape[0])
+        assert (gdu[0::2] == even).all() and (gdu[1::2] == flags).all() and (filt == want_filter).all()
+        assert int(flags.astype(np.uint64).sum()) == 0   # nobody is the only site of its key
+        info = ix.info()
+        n_sites = sum(len(v) for v in sites.values())
+        assert info["n_keys"] == len(sites) and info["n_sites"] == n_sites and info["n_unique"] == 0
+        if copies <= 5:
+            assert info["n_dupe_keys"] == len(sites) and info["n_dupe_sites"] == n_sites and info["n_high_keys"] == 0
+        else:
+            assert info["n_dupe_keys"] == 0 and info["n_dupe_sites"] == 0 and info["n_high_keys"] == len(sites)
+
+        def ref_kmer(key):   # device key -> indexer.rs:789-913 coding
+            out = 0
+            for k in range(16):
+                out = (out << 2) | {0: 0, 1: 2, 2: 1, 3: 3}[(key >> (2 * k)) & 3]
+            return out
+        keys = list(sites.keys())
+        sample = [keys[i] for i in rng.choice(len(keys), size=2000, replace=False)]
+        cnt, ctg, pos = ix.lookup(np.array([ref_kmer(k) for k in sample], dtype=np.uint32))
+        for j, k in enumerate(sample):
+            if copies <= 5:
+                got = [int(lin_base[int(ctg[j, t])]) + int(pos[j, t]) for t in range(copies)]
+                assert int(cnt[j]) == copies and got == sorted(sites[k])
+            else:
+                assert int(cnt[j]) == -2
+    finally:
+        ix.close()
+
+
 def test_export_rejects_unknown_array(gpu_device):
     from genefuserust_amd import Indexer, _lib
     ix = Indexer.from_gene_slices([b"ACGTTGCA" * 8])
