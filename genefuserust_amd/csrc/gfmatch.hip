@@ -429,11 +429,12 @@ struct FlatPlan {
 // beyond the flat kernels' limit
 static FlatPlan flat_plan(int64_t n, int n_cus, int pw, bool long_reads) {
   FlatPlan p;
-  // Up to 32 blocks per CU, but 3 K reads a block at least and whole rounds of the four blocks a CU runs at a time:
+  // Up to 32 blocks per CU, but about 3 K reads a block at least and whole rounds of the four blocks a CU runs at a time:
   // 20 M reads in 6144 blocks were 1.4 % faster than in 8192 (the list kernels pay per block: 0.155 -> 0.133 ms),
   // 200 M reads in 8192 blocks 0.4 % faster than in 6144 (r03 b; GF_NBLK_MULT sets blocks per CU outright: experiments)
-  int64_t nblk = std::min<int64_t>((int64_t)n_cus * 32, n / 3072);
-  nblk = std::max<int64_t>(nblk / ((int64_t)n_cus * 4) * ((int64_t)n_cus * 4), (int64_t)n_cus * 4);
+  const int64_t round_blocks = (int64_t)n_cus * 4;
+  int64_t nblk = std::min<int64_t>((int64_t)n_cus * 32, (n / 3072 + round_blocks / 2) / round_blocks * round_blocks);  // (the nearest whole round)
+  nblk = std::max<int64_t>(nblk, round_blocks);
   if (const char* e = getenv("GF_NBLK_MULT")) nblk = (int64_t)n_cus * std::max(1, atoi(e));
   p.nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, nblk));
   p.per_block = (n + p.nblk - 1) / p.nblk;
