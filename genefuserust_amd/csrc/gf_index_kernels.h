@@ -7,10 +7,11 @@
 // (position -(f+15), windows 1..len-16; the reverse window i of indexer.rs:168
 // is the forward window f = len-16-i, so position = i+1-len = -(f+15)).
 // Keys seen once keep their site, 2..5 times keep all sites, >= 6 times become
-// HIGH.  No sort.  One pass over the gene bases (gf_k_index_insert: a key's first site is written with the
+// HIGH.  No sort.  The presence filter by hash partitions (gf_k_filter_scatter / gf_k_filter_build: no global
+// atomics), one pass over the gene bases (gf_k_index_insert: a key's first site is written with the
 // claim of its slot, later sites go to a side list), a sweep over the table (counters -> unique /
-// dupes(start in dupes[]) / HIGH, statistics), the side list into the duplicate lists.  The first form is kept
-// behind GF_BUILD_TWO_PASS (experiments):
+// dupes(start in dupes[]) / HIGH, statistics), the side list into the duplicate lists (each sorted by the thread
+// that brings its last site).  The first form is kept behind GF_BUILD_TWO_PASS (experiments):
 //   COUNT   insert keys with 64-bit CAS, count occurrences
 //   classify (count -> unique / dupes(start in dupes[]) / HIGH)
 //   FILL    write site codes
