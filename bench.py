@@ -87,6 +87,29 @@ def usable_cores() -> int:
     return cores
 
 
+def kernel_source_sha() -> str:
+    """What the kernels and their launch geometry are made of: sha256 over genefuserust_amd/csrc/* and include/gfmatch.h
+    (sorted by name).  tools/make_traffic.py stamps every profiles/hbm_traffic.json entry with it; a line whose loaded
+    sources differ from the entry's says `traffic_stale: true`."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "genefuserust_amd", "csrc")
+    files = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hip")) or f == "Makefile")
+    files.append(os.path.join(ROOT, "include", "gfmatch.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def library_sha() -> str:
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "genefuserust_amd", "libgfmatch.so"), "rb").read()).hexdigest()[:16]
+    except Exception:
+        return "absent"
+
+
 def traffic_entry(shape: str, n: int, L: int):
     """Counter-measured fabric bytes per launch for this workload (profiles/hbm_traffic.json), or None."""
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -157,6 +180,8 @@ def main() -> None:
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-packed", action="store_true", help="config 4: map the ASCII reads per CSV instead of packing them once")
+    ap.add_argument("--no-pack-sweep", action="store_true", help="skip the boundary sweep (packs x host threads through the C ABI)")
+    ap.add_argument("--no-stress", action="store_true", help="skip the stress rows (repeat-rich genes, outside the timed region)")
     ap.add_argument("--reads", default="pairs", choices=["pairs", "independent"],
                     help="pairs (default): synth.make_pair_reads, SURVEY.md 8(d); independent: synth.make_reads (r01/r02's workload)")
     ap.add_argument("--profile-mode", action="store_true", help="only warm-up + timed passes (for rocprofv3 runs): no CPU baseline, "
@@ -168,7 +193,7 @@ def main() -> None:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))   # (nothing has touched the GPU yet)
     if args.profile_mode:
-        args.no_cpu_baseline = args.no_parity = args.no_h2d = True
+        args.no_cpu_baseline = args.no_parity = args.no_h2d = args.no_pack_sweep = args.no_stress = True
     cfg = dict(CONFIGS[args.config])
     if args.shape:
         cfg["shape"] = args.shape
@@ -260,6 +285,7 @@ def main() -> None:
                  torch.empty(cws, dtype=torch.uint8, device=dev)) for _ in range(2)]
     step_no = [0]
     exch = None
+    ranks_seen = [dist.get_world_size() if world > 1 else 1]   # N > 1 over RCCL: what gf_comm_rank reports (below)
     exchange_name = "none (single GPU)"
     if world > 1:
         if rehearsal or os.environ.get("GF_BENCH_PLAIN_ALLGATHER") == "1":
@@ -273,26 +299,19 @@ def main() -> None:
             mx = nh.clone()
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             cap_x = min(max(4096, 2 * int(mx.item())), max(n // 16, 1))
-            err = None
+            # A communicator that cannot be made, or cannot move data, fails the run on EVERY rank (RcclHitExchange agrees
+            # over the torch group after each step that can fail on one rank alone): no switch to another path inside a
+            # process that has touched the GPU.  GF_BENCH_PLAIN_ALLGATHER=1 is the explicit opt-out.
             try:
                 exch = RcclHitExchange(cap=cap_x, device=dev)
-                # one exchange before anything is timed: a communicator that cannot move data fails here, on every rank
-                exch.finish(exch.start(out_sets[0][0], nh))
-                torch.cuda.synchronize()
-                exchange_name = ("gf_allgather_hits_device: one ncclAllGather of %d-record blocks through the C ABI, on a side "
-                                 "stream, pipelined one step deep" % exch.cap)
-            except Exception as e:  # noqa: BLE001 — never silent: the line names the path that was timed and why
-                err = e
-                print("rank %d: RCCL exchange through the C ABI failed (%s: %s)" % (rank, type(e).__name__, e),
-                      file=sys.stderr, flush=True)
-            # the ranks agree: one rank on another path would leave the others waiting in a collective nobody joins
-            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                from genefuserust_amd.dist import HitExchange
-                exch = _TorchExchange(HitExchange(cap=cap_x, device=dev))
-                exchange_name = ("FALLBACK (gf_allgather_hits_device failed on a rank%s): HitExchange over torch.distributed, one "
-                                 "asynchronous fixed-capacity all-gather" % ("" if err is None else ": " + type(err).__name__))
+                exch.first_exchange(out_sets[0][0], nh)
+            except Exception as e:  # noqa: BLE001
+                print("rank %d: RCCL exchange through the C ABI failed (%s: %s); rerun with GF_BENCH_PLAIN_ALLGATHER=1 to "
+                      "take torch.distributed's all-gather instead" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+                os._exit(3)   # (a peer's collective may still be waiting on the device: no destructors)
+            ranks_seen[0] = exch.comm_world()[1]
+            exchange_name = ("gf_allgather_hits_device: one ncclAllGather of %d-record blocks through the C ABI, on a side "
+                             "stream, pipelined one step deep" % exch.cap)
 
     def step(ev=None):
         if ev is not None:
@@ -454,6 +473,7 @@ def main() -> None:
             "index_build_s": round(t_index, 3),
             "hits_per_step": n_hits_total,
             "exchange": exchange_name,
+            "ranks_seen": ranks_seen[0],
             "parallelism": "reads sharded over %d rank(s), index replicated, all-gather of hit records" % world
                            if world > 1 else "single GPU",
         },
@@ -488,6 +508,11 @@ def main() -> None:
             result["packed_input"] = packed_ms
         if fixed_ms:
             result["fixed_length_input"] = fixed_ms
+        if world == 1 and not args.no_pack_sweep:
+            try:
+                result["pack_sweep"] = pack_sweep(genes, reads, n, L)
+            except Exception as e:  # noqa: BLE001 — a reported extra, never the value
+                result["pack_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # ---- parity spot check + CPU baseline (oracle = CPU restatement; never on the product path) ----
         want_cpu = world == 1 and not args.no_cpu_baseline
         want_parity = not args.no_parity
@@ -496,16 +521,25 @@ def main() -> None:
             ox = oracle_py.OracleIndexer(genes.seqs)
             cores = usable_cores()
             if want_parity:
-                ns = min(n, 400_000)
-                b = reads.bases[: ns * L].cpu().numpy()
-                o = reads.offsets[: ns + 1].cpu().numpy()
+                # every read of this rank's step that came back with segments, plus 100 K reads drawn at random, re-mapped
+                # by the oracle (what tests/test_gpu_parity.py::test_full_size_properties does)
+                hit_ids = ((counts > 0) & (counts < 255)).nonzero().flatten()
+                g = torch.Generator(device="cpu")
+                g.manual_seed(1234)
+                sample = torch.randint(0, n, (min(n, 100_000),), generator=g).to(dev)
+                ids = torch.unique(torch.cat([hit_ids, sample]))   # (sorted)
+                ns = int(ids.numel())
+                b = reads.bases.view(n, L)[ids].reshape(-1).cpu().numpy()
+                o = np.arange(ns + 1, dtype=np.int64) * L
                 oc, om = ox.map_reads_packed(b, o, threads=cores)
-                gc = counts[:ns].cpu().numpy().astype(np.int32)
-                gm = matches[:ns].cpu().numpy().view(om.dtype).reshape(ns, 2)
+                gc = counts[ids].cpu().numpy().astype(np.int32)
+                gm = matches[ids].cpu().numpy().view(om.dtype).reshape(ns, 2)
                 ok = bool((gc == oc).all())
                 nz = oc > 0
                 ok = ok and bool((gm[nz, 0] == om[nz, 0]).all()) and bool((gm[oc == 2, 1] == om[oc == 2, 1]).all())
-                result["parity"] = {"checked_reads": ns, "bit_exact": ok, "reads_with_segments": int(nz.sum())}
+                result["parity"] = {"checked_reads": ns, "bit_exact": ok, "reads_with_segments": int(nz.sum()),
+                                    "gpu_reads_with_segments": int(hit_ids.numel()),
+                                    "what": "every read of the step with segments + 100 000 reads drawn at random, re-mapped by the oracle"}
             if want_cpu:
                 result["cpu_baseline"] = cpu_baseline(ox, reads, n, L, cores, args.cpu_seconds)
         print(json.dumps(result), flush=True)
@@ -528,8 +562,13 @@ def roofline_object(args, cfg, n, L, kern_ms_avg, stage_ms):
     algo = algo_bytes_per_read(L) * n  # bytes per launch
     algo_gbps = algo / secs / 1e9
     comp_gbps = COMPULSORY_BYTES_PER_READ(L) * n / secs / 1e9
-    te = traffic_entry(cfg["shape"], n, L) if args.scale == 1.0 and args.mix == "PANEL" else None
+    # the counter entry is of the default workload only: PANEL pair reads, default gene synthesis, flat pipeline
+    default_workload = (args.scale == 1.0 and args.mix == "PANEL" and args.reads == "pairs" and args.variant == 0
+                        and args.repeat_frac is None and not args.low_complexity)
+    te = traffic_entry(cfg["shape"], n, L) if default_workload else None
     traffic = te["hbm_bytes_per_launch"] if te else None
+    src_sha = kernel_source_sha()
+    stale = bool(te) and te.get("kernel_src_sha") != src_sha
     measured = traffic / secs / 1e9 if traffic else None
     achieved = measured if measured is not None else algo_gbps
     return {
@@ -547,11 +586,20 @@ def roofline_object(args, cfg, n, L, kern_ms_avg, stage_ms):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "frac_definition": ("measured: (32 B x TCC_EA0_RDREQ_DRAM_32B + WRITE_SIZE) per pass / kernel time / 8 TB/s"
+        "frac_definition": ("measured: L2 <-> fabric bytes (incl. Infinity-Cache hits) = (32 B x TCC_EA0_RDREQ_DRAM_32B + WRITE_SIZE) "
+                            "per pass / kernel time / 8 TB/s"
                             if measured is not None else
                             "ALGORITHMIC (no counter measurement for this workload): 706 B per read / kernel time / 8 TB/s"),
         "traffic": traffic,
         "traffic_source": (te or {}).get("source"),
+        "traffic_build": None if not te else {"git_head": te.get("git_head"), "kernel_src_sha": te.get("kernel_src_sha"),
+                                              "lib_sha": te.get("lib_sha")},
+        "traffic_stale": stale if te else None,
+        "loaded_build": {"kernel_src_sha": src_sha, "lib_sha": library_sha()},
+        "hbm_only": None,
+        "hbm_only_note": "not separable: rocprofv3 on gfx950 exposes the CPC CPF GRBM SPI SQ TA TCA TCC TCP TD blocks only "
+                         "(counter_defs.yaml) - no Infinity-Cache (MALL) or memory-controller counter; TCC_EA0_RDREQ_DRAM* counts "
+                         "requests 'destined for DRAM' whether the Infinity Cache or HBM serves them",
         "traffic_read_bytes": (te or {}).get("read_bytes_per_launch"),
         "traffic_write_bytes": (te or {}).get("write_bytes_per_launch"),
         "algorithmic_GBps": algo_gbps,
@@ -596,6 +644,37 @@ def cpu_baseline(ox, reads, n, L, cores, cpu_seconds):
                   "%d threads pulling 1000-read packs); %.1f s" % (ns, cores, dt),
         "value_4_threads": t4,
     }
+
+
+def pack_sweep(genes, reads, n, L):
+    """The boundary at the reference's granularity (never `value`): packs of P pairs x T host threads through the C ABI —
+    gf_map_reads_hits and gf_stream_submit / collect, pageable and pinned sources — by tools/pack_sweep.cpp in a child
+    process on the first 8 M reads of the batch.  The reference: PACK_SIZE = 1000 pairs (common.rs:23), one
+    Indexer::map_read per read from t-1 consumer threads (pescanner.rs:296-311, 374-518)."""
+    from tools.bench_pack_sweep import run_sweep
+    ns = min(n, 8_000_000)
+    j = run_sweep(genes.seqs, reads.bases[: ns * L].cpu().numpy(), reads.offsets[: ns + 1].cpu().numpy(), seconds=0.2,
+                  extra=["--packs", "125,250,500,1000,4000,16000,64000,256000,1000000"])
+    cells = j["cells"]
+    threads = sorted({c["threads"] for c in cells})
+    packs = sorted({c["pack_pairs"] for c in cells})
+    tab = {}
+    for c in cells:
+        key = "%s, %s" % (c["entry"], c["mem"])
+        tab.setdefault(key, {p: [None] * len(threads) for p in packs})[c["pack_pairs"]][threads.index(c["threads"])] = \
+            round(c["reads_per_s"] / 1e6, 1)
+    smallest = {}
+    for key, rows in tab.items():
+        if 8 in threads:
+            ok = [p for p in packs if (rows[p][threads.index(8)] or 0) >= 50.0]
+            smallest[key] = ok[0] if ok else None
+    return {"unit": "M reads/s", "threads": threads, "pack_pairs": packs,
+            "rows": {k: {str(p): v for p, v in rows.items()} for k, rows in tab.items()},
+            "smallest_pack_pairs_with_8_threads_over_50M_reads_per_s": smallest,
+            "us_per_single_read_call": j["us_per_single_read_call"], "seconds_per_cell": j["seconds_per_cell"],
+            "reads": ns,
+            "what": "tools/pack_sweep.cpp through the C ABI only: T threads on one index, each mapping packs of P pairs (2 P reads); "
+                    "calls of up to 8192 reads take the zero-copy route (one launch), larger ones the batch route"}
 
 
 def h2d_inclusive(ix, reads, n, L):

@@ -219,6 +219,8 @@ def lib() -> C.CDLL:
     L.gf_last_stage_ms.restype = C.c_int
     L.gf_set_map_variant.argtypes = [vp, i32]
     L.gf_set_map_variant.restype = C.c_int
+    L.gf_set_pack_call_reads.argtypes = [vp, C.c_int64]
+    L.gf_set_pack_call_reads.restype = C.c_int
     L.gf_last_map_kernel_ms.argtypes = [vp]
     L.gf_last_map_kernel_ms.restype = C.c_float
     _lib = L

@@ -416,7 +416,7 @@ __device__ __forceinline__ int gf_first_pass_seed_verify(const GfTable& T, GfMap
 template <int LCAP>
 __device__ __forceinline__ void gf_segment_mask_wave(GfMapSmem<LCAP>& S, int L, int lane, int64_t gp1, int64_t gp2,
                                                      int64_t r, uint8_t* __restrict__ counts,
-                                                     gf_seqmatch* __restrict__ matches) {
+                                                     gf_seqmatch* __restrict__ matches, bool zc = false) {
   constexpr int NCH = (LCAP + 63) / 64;
   uint32_t* segT = (uint32_t*)S.u.p2.wcls;        // wcls is dead: reuse it for the masks (32-bit halves)
   uint32_t* segH = segT + 2 * NCH;
@@ -501,7 +501,16 @@ __device__ __forceinline__ void gf_segment_mask_wave(GfMapSmem<LCAP>& S, int L, 
       nout += 1;
     }
   }
-  if (lane == 0) counts[r] = (uint8_t)nout;
+  if (!zc) {
+    if (lane == 0) counts[r] = (uint8_t)nout;
+  } else if (nout > 0) {
+    // a zero-copy host call (GfTable::done_*): counts start out zero in the host's pinned block and only a read WITH
+    // segments writes anything; its wave then makes those few stores visible system-wide before it goes on, so that
+    // the word the grid's last block stores cannot overtake them.  (A fence per wave, hits or not, made concurrent
+    // callers' kernels take turns; waiting for the stores' acknowledgements alone let the word overtake them.)
+    if (lane == 0) counts[r] = (uint8_t)nout;
+    __threadfence_system();
+  }
 }
 
 // ---- 3..5: peel, gate, second pass, segment_mask, output ----
@@ -511,7 +520,7 @@ __device__ __forceinline__ void gf_finish_read(const GfTable& T, GfMapSmem<LCAP>
                                                gf_seqmatch* __restrict__ matches) {
   // count1 >= 20 and count2 >= 10 on two different diagonals need >= 30 votes
   if (nvotes < (GF_MAJOR_KEYS + GF_MINOR_KEYS) / 2) {
-    if (lane == 0) counts[r] = 0;
+    if (lane == 0 && T.done_flag == nullptr) counts[r] = 0;  // (a zero-copy call's counts start out zero)
     return;
   }
   gf_wave_lds_sync();
@@ -556,7 +565,7 @@ __device__ __forceinline__ void gf_finish_read(const GfTable& T, GfMapSmem<LCAP>
     }
   }
   if (cnt1 * 2 < GF_MAJOR_KEYS || cnt2 * 2 < GF_MINOR_KEYS) {
-    if (lane == 0) counts[r] = 0;
+    if (lane == 0 && T.done_flag == nullptr) counts[r] = 0;  // (a zero-copy call's counts start out zero)
     return;
   }
 
@@ -633,12 +642,29 @@ __device__ __forceinline__ void gf_finish_read(const GfTable& T, GfMapSmem<LCAP>
     mismatches += __popcll(__ballot(j < L && m <= 1));
   }
   if (mismatches > GF_MISMATCH_THRESHOLD) {
-    if (lane == 0) counts[r] = 0;
+    if (lane == 0 && T.done_flag == nullptr) counts[r] = 0;  // (a zero-copy call's counts start out zero)
     return;
   }
   gf_wave_lds_sync();
 
-  gf_segment_mask_wave<LCAP>(S, L, lane, gp1, gp2, r, counts, matches);
+  gf_segment_mask_wave<LCAP>(S, L, lane, gp1, gp2, r, counts, matches, T.done_flag != nullptr);
+}
+
+// End of a kernel of a zero-copy host call (GfTable::done_*): the block's results are made visible system-wide, the
+// block counts itself out, the last block of the grid resets the counter and tells the host.  Every thread of the
+// block reaches this (no early exits before it).
+__device__ __forceinline__ void gf_block_done(const GfTable& T) {
+  if (T.done_ctr == nullptr) return;  // (uniform)
+  // (the waves that wrote results have fenced them at system scope where they wrote them, gf_segment_mask_wave)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int old = atomicAdd(T.done_ctr, 1u);
+    if (old == gridDim.x - 1) {
+      __hip_atomic_store(T.done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the lane's next call finds it zero
+      __threadfence_system();
+      __hip_atomic_store(T.done_flag, T.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // PRODUCER: 0 = probe all windows, 1 = seed + verify (LCAP <= 256 only)
@@ -660,7 +686,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf_k_map_reads(GfTable T, const ui
     const int64_t off0 = offsets[r];
     const int64_t len64 = offsets[r + 1] - off0;
     if (T.skip != nullptr && T.skip[r] > 0) {  // not a candidate of this pass (gf_table.h: skip)
-      if (lane == 0) counts[r] = 0;
+      if (lane == 0 && T.done_flag == nullptr) counts[r] = 0;  // (a zero-copy call's counts start out zero)
       continue;
     }
     if (len64 > LCAP) {
@@ -670,7 +696,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf_k_map_reads(GfTable T, const ui
     if (len64 <= lmin) continue;
     const int L = (int)len64;
     if (L < GF_KMER) {  // no window (also covers malformed negative lengths)
-      if (lane == 0) counts[r] = 0;
+      if (lane == 0 && T.done_flag == nullptr) counts[r] = 0;  // (a zero-copy call's counts start out zero)
       continue;
     }
     gf_wave_lds_sync();  // previous read's LDS traffic is finished
@@ -681,6 +707,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf_k_map_reads(GfTable T, const ui
     else nvotes = gf_first_pass_probe_all<LCAP>(T, S, L, sh, lane);
     gf_finish_read<LCAP>(T, S, L, sh, nvotes, lane, r, counts, matches);
   }
+  gf_block_done(T);
 }
 
 // The <= 256-base class with a two-deep software pipeline over the reads of a wave:
@@ -700,7 +727,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void gf_k_map_reads_short(GfTable T,
   GfMapSmem<LCAP>& S = smem[wib];
   const int64_t stride = (int64_t)gridDim.x * WAVES;
   const int64_t r0 = (int64_t)blockIdx.x * WAVES + wib;
-  if (r0 >= n) return;
+  if (r0 >= n) {  // (a wave without a read; it still counts its block out)
+    gf_block_done(T);
+    return;
+  }
 
   // pipeline registers: [cur] bases loaded, [nxt] offsets loaded
   int64_t cur_off = offsets[r0], cur_end = offsets[r0 + 1];
@@ -738,11 +768,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void gf_k_map_reads_short(GfTable T,
 
     const int64_t len64 = cur_end - cur_off;
     if (T.skip != nullptr && T.skip[r] > 0) {  // not a candidate of this pass (gf_table.h: skip)
-      if (lane == 0) counts[r] = 0;
+      if (lane == 0 && T.done_flag == nullptr) counts[r] = 0;  // (a zero-copy call's counts start out zero)
     } else if (len64 > LCAP) {
       if (mark_too_long && lane == 0) counts[r] = GF_COUNT_TOO_LONG;
     } else if (len64 < GF_KMER) {
-      if (lane == 0) counts[r] = 0;
+      if (lane == 0 && T.done_flag == nullptr) counts[r] = 0;  // (a zero-copy call's counts start out zero)
     } else {
       const int L = (int)len64;
       const uint32_t sh = (uint32_t)((uintptr_t)(bases + cur_off) & 3u);
@@ -763,6 +793,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void gf_k_map_reads_short(GfTable T,
     cur_off = nxt_off; cur_end = nxt_end; cur_x0 = nxt_x0; cur_x1 = nxt_x1;
     nxt_off = nn_off; nxt_end = nn_end;
   }
+  gf_block_done(T);
 }
 
 // Test/diagnostic: the device form of segment_mask alone, on class masks given by the caller (one

@@ -96,6 +96,14 @@ struct GfTable {
   // of the batch: gf_scan_pairs_device's merged reads, compacted to the front of a batch of n slots whose number the
   // host does not know).  Seed+verify then does not walk the empty slots (r03 b: 0.3 of 0.55 ms per 10 M pairs).
   const int64_t* n_dev;
+  // per-call, optional (the wave-per-read kernels of a zero-copy host call, gfmatch.hip zc_submit).  done_flag set:
+  // counts / matches are pinned host memory whose counts start out zero — only reads with segments are written, each
+  // followed by a system-scope fence of its wave.  done_ctr set as well (the call's last launch): every block counts
+  // itself out on it, and the last one stores done_seq to done_flag — the host waits on that word instead of a
+  // stream synchronisation.
+  unsigned int* done_ctr;
+  unsigned int* done_flag;
+  uint32_t done_seq;
 };
 
 // filter word and bit pair of a 14-mer x (28 bits).  One multiplicative hash: the word comes

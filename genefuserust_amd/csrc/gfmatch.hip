@@ -15,6 +15,7 @@
 #include <memory>
 #include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -263,6 +264,7 @@ struct gf_index {
   // first pass for reads <= 256 bases: 0 = flat pipeline (pack, seed+verify, probe, exact
   // kernel on survivors), 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify
   int map_variant = 0;
+  int64_t pack_call_reads = -1;  // host calls of up to this many reads take the zero-copy route (-1: GF_PACK_CALL_READS / the default)
   // Indexer.m_fusion_seq (indexer.rs:77, :170): the upper-cased gene slices.  The device keeps them (d_cat, one
   // concatenation: the build's own input, upper-cased there); the host copy of a gene is fetched on first use —
   // in multi-CSV mode an index lives for one pass over the reads and only the genes of its few hits are ever asked for
@@ -994,6 +996,40 @@ static int segment_mask_test_impl(const gf_index* idx, const uint8_t* masks, con
   return GF_OK;
 }
 
+// The exact wave-per-read kernels over a whole batch (gf_map_kernels.h): one launch per read-length class present
+// (<= 256, <= 1024, <= 4096 bases), each skipping the reads of the other classes.  producer: 0 = probe every window,
+// 1 = seed + verify (the <= 256 class).  top = the batch's highest class.
+static void launch_wave_per_read(const GfTable& T_in, hipStream_t st, int n_cus, const uint8_t* bases, const int64_t* offsets, int64_t n,
+                                 int top, int producer, uint8_t* counts, gf_seqmatch* matches) {
+  // a zero-copy call's completion word (GfTable::done_*) is stored by the LAST launch only: the stream runs them in order
+  GfTable Tq = T_in;
+  Tq.done_ctr = nullptr;  // (done_flag stays: the earlier launches write a zero-copy call's results the same way)
+  {
+    const GfTable& T = top == 0 ? T_in : Tq;
+    constexpr int W = 4;
+    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)n_cus * 8);
+    if (producer == 0)
+      hipLaunchKernelGGL((gf_k_map_reads_short<W, 0>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
+                         n, top == 0 ? 1 : 0, counts, matches);
+    else
+      hipLaunchKernelGGL((gf_k_map_reads_short<W, 1>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
+                         n, top == 0 ? 1 : 0, counts, matches);
+  }
+  if (top >= 1) {
+    const GfTable& T = top == 1 ? T_in : Tq;
+    constexpr int W = 4;
+    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)n_cus * 4 * 2);
+    hipLaunchKernelGGL((gf_k_map_reads<1024, W, 0>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
+                       n, 256, top == 1 ? 1 : 0, counts, matches);
+  }
+  if (top >= 2) {
+    constexpr int W = 2;
+    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)n_cus * 2 * 2);
+    hipLaunchKernelGGL((gf_k_map_reads<4096, W, 0>), dim3(grid), dim3(W * 64), 0, st, T_in, bases, offsets,
+                       n, 1024, 1, counts, matches);
+  }
+}
+
 static int map_span_device(const gf_index* idx, const ReadSrc& src, const int64_t* offsets, int64_t n,
                            int32_t max_read_len, uint8_t* counts, gf_seqmatch* matches, hipStream_t st, bool prof,
                            const int32_t* skip, int32_t fixed_len = 0, const int64_t* n_dev = nullptr) {
@@ -1036,26 +1072,7 @@ static int map_span_device(const gf_index* idx, const ReadSrc& src, const int64_
     if (wrc != GF_OK) return wrc;
     if (prof) mix->stages_recorded = true;
   } else {
-    constexpr int W = 4;
-    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 8);
-    if (idx->map_variant == 1)
-      hipLaunchKernelGGL((gf_k_map_reads_short<W, 0>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
-                         n, top == 0 ? 1 : 0, counts, matches);
-    else
-      hipLaunchKernelGGL((gf_k_map_reads_short<W, 1>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
-                         n, top == 0 ? 1 : 0, counts, matches);
-  }
-  if (top >= 1 && idx->map_variant != 0) {
-    constexpr int W = 4;
-    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 4 * 2);
-    hipLaunchKernelGGL((gf_k_map_reads<1024, W, 0>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
-                       n, 256, top == 1 ? 1 : 0, counts, matches);
-  }
-  if (top >= 2 && idx->map_variant != 0) {
-    constexpr int W = 2;
-    int grid = (int)std::min<int64_t>((n + W - 1) / W, (int64_t)idx->n_cus * 2 * 2);
-    hipLaunchKernelGGL((gf_k_map_reads<4096, W, 0>), dim3(grid), dim3(W * 64), 0, st, T, bases, offsets,
-                       n, 1024, 1, counts, matches);
+    launch_wave_per_read(T, st, idx->n_cus, bases, offsets, n, top, idx->map_variant == 1 ? 0 : 1, counts, matches);
   }
   GF_HIP(hipGetLastError());
   return GF_OK;
@@ -1238,12 +1255,51 @@ int gf_compact_hits_device(const gf_index* idx, const void* d_counts, const void
 // overlap instead of queueing behind one mutex; a caller waits only when all lanes are taken.
 // (For a PCIe-bound path the per-call hipMalloc/hipFree of gigabyte buffers cost as much as the
 // copies: hence the arenas.)
+// Blocks handed out by gf_host_alloc: a zero-copy call whose reads lie in one of them lets its kernel read them where
+// they are (no staging memcpy).  Few entries, looked up under a shared lock.
+struct PinnedBlock {
+  const char* host;
+  size_t bytes;
+  const uint8_t* dev;
+};
+static std::vector<PinnedBlock> g_pinned;
+static std::shared_mutex g_pinned_mu;
+static const uint8_t* pinned_device_address(const char* p, size_t len) {
+  std::shared_lock<std::shared_mutex> lk(g_pinned_mu);
+  for (const PinnedBlock& b : g_pinned)
+    if (p >= b.host && p + len <= b.host + b.bytes) return b.dev + (p - b.host);
+  return nullptr;
+}
+
+// A zero-copy call: reads staged in (or read straight from) pinned host memory, ONE launch of the exact
+// wave-per-read kernels that fetches them over the link and writes counts and matches back into the same pinned
+// block, completion reported by a word the kernel's last block stores (GfTable::done_*) — no copy commands, no
+// stream synchronisation.  A lane of the host-buffer calls and a slot of a gf_stream each own one.
+struct ZeroCopy {
+  uint8_t* pinned = nullptr;    // host: | completion word (64 B) | offsets | matches | counts | bases |
+  uint8_t* d_pinned = nullptr;  // the same block as the device addresses it
+  size_t pinned_bytes = 0;
+  unsigned int* d_done_ctr = nullptr;  // device: the blocks count themselves out here
+  uint32_t seq = 0;                    // number of the last call = the value its kernel stores to the completion word
+  uint32_t unsynced = 0;               // calls since the stream was last synchronised
+  // the call in flight (zc_submit .. zc_wait)
+  const uint8_t* h_counts = nullptr;
+  const gf_seqmatch* h_matches = nullptr;
+  bool flag_wait = false;
+  void release() {
+    if (pinned) (void)hipHostFree(pinned);
+    if (d_done_ctr) (void)hipFree(d_done_ctr);
+    pinned = d_pinned = nullptr;
+    d_done_ctr = nullptr;
+    pinned_bytes = 0;
+  }
+};
+
 struct HostLane {
   hipStream_t st = nullptr;
   void* arena = nullptr;
   size_t arena_bytes = 0;
-  uint8_t* pinned = nullptr;  // host, pinned + device-visible: results of small calls, totals
-  size_t pinned_bytes = 0;
+  ZeroCopy zc;  // the reads and results of zero-copy calls
   bool busy = false;
 };
 
@@ -1260,7 +1316,7 @@ static const int GF_MAX_LANES = 8;
 void gf_index::free_lanes() {  // (the destructor has waited for the device)
   for (HostLane* L : lanes) {
     if (L->arena) (void)hipFree(L->arena);
-    if (L->pinned) (void)hipHostFree(L->pinned);
+    L->zc.release();
     if (L->st) {
       // every host-buffer call went through gf_map_reads_device(L->st): its mapping workspace (64-112 B per read of
       // the largest batch) is keyed by this stream in the process-wide pool and would outlive it — a host that
@@ -1337,17 +1393,25 @@ static int lane_reserve(HostLane& L, size_t need) {
   return GF_OK;
 }
 
-static int lane_reserve_pinned(HostLane& L, size_t need) {
-  if (L.pinned_bytes >= need) return GF_OK;
-  if (L.pinned) {
-    GF_HIP(hipStreamSynchronize(L.st));
-    GF_HIP(hipHostFree(L.pinned));
-    L.pinned = nullptr;
-    L.pinned_bytes = 0;
+static int zc_reserve(ZeroCopy& Z, hipStream_t st, size_t need) {
+  if (!Z.d_done_ctr) {
+    GF_HIP(hipMalloc((void**)&Z.d_done_ctr, 256));
+    GF_HIP(hipMemset(Z.d_done_ctr, 0, 256));
   }
-  need = std::max<size_t>(need, 64 * 1024);
-  GF_HIP(hipHostMalloc((void**)&L.pinned, need, hipHostMallocDefault));
-  L.pinned_bytes = need;
+  if (Z.pinned_bytes >= need) return GF_OK;
+  if (Z.pinned) {
+    GF_HIP(hipStreamSynchronize(st));
+    GF_HIP(hipHostFree(Z.pinned));
+    Z.pinned = nullptr;
+    Z.pinned_bytes = 0;
+  }
+  need = std::max<size_t>(need + need / 4, 64 * 1024);
+  GF_HIP(hipHostMalloc((void**)&Z.pinned, need, hipHostMallocDefault));
+  Z.pinned_bytes = need;
+  void* dptr = nullptr;
+  GF_HIP(hipHostGetDevicePointer(&dptr, Z.pinned, 0));
+  Z.d_pinned = (uint8_t*)dptr;
+  *(volatile uint32_t*)Z.pinned = Z.seq;  // the completion word (first 64 bytes of the block)
   return GF_OK;
 }
 
@@ -1390,10 +1454,14 @@ static int stage_and_map(gf_index* mix, HostLane& L, const char* bases, const in
                              (void*)L.st);
 }
 
-// Calls of a few reads — Indexer::map_read as the reference calls it, one read at a time — skip the
-// copies altogether: the reads are written to the lane's pinned block, ONE launch of the exact
-// wave-per-read kernel fetches them over the link and writes its result back to the same block.
-// (The batch route is an H2D copy, five launches and a D2H copy for the same answer.)
+// Calls of a few reads — Indexer::map_read as the reference calls it, one read at a time — and calls of one PACK
+// of the reference's size (PACK_SIZE = 1000 pairs, common.rs:23; pescanner.rs:427-518) skip the copies altogether:
+// the reads are written to the lane's pinned block, the exact wave-per-read kernels fetch them over the link and
+// write their results back to the same block: ONE launch and one wait per call where the batch route is two
+// copies in, a memset, seven launches and two copies out — 12 queue operations whose cost, not the kernels', is
+// what a 2000-read call pays for (tools/bench_pack_sweep.py).
+//   n <= GF_SMALL_CALL_READS (64):     one wave per read, probe-all kernel, a block per read
+//   n <= GF_PACK_CALL_READS:           the software-pipelined seed+verify kernel, grid-stride over the pack
 static int64_t small_call_reads() {
   static const int64_t v = [] {
     int64_t d = 64;
@@ -1403,9 +1471,24 @@ static int64_t small_call_reads() {
   return v;
 }
 #define GF_SMALL_CALL_READS small_call_reads()
+#ifndef GF_PACK_CALL_READS_DEFAULT
+#define GF_PACK_CALL_READS_DEFAULT 8192  // (reads: packs of up to 4096 pairs; the crossover is measured by tools/bench_pack_sweep.py)
+#endif
+static int64_t pack_call_reads() {
+  static const int64_t v = [] {
+    int64_t d = GF_PACK_CALL_READS_DEFAULT;
+    if (const char* e = getenv("GF_PACK_CALL_READS")) d = std::max<int64_t>(0, atoll(e));  // 0 = the batch route for every call beyond the small ones
+    return d;
+  }();
+  return v;
+}
+static inline bool zero_copy_call(const gf_index* idx, int64_t n) {
+  const int64_t lim = idx->pack_call_reads >= 0 ? idx->pack_call_reads : pack_call_reads();
+  return idx->map_variant == 0 && n > 0 && (n <= GF_SMALL_CALL_READS || n <= lim);
+}
 
-static int map_small(gf_index* mix, HostLane& L, const char* bases, const int64_t* offsets, int64_t n,
-                     const uint8_t** out_counts, const gf_seqmatch** out_matches) {
+// validates the pack, stages it, queues its one launch on `st`
+static int zc_submit(gf_index* mix, ZeroCopy& Z, hipStream_t st, const char* bases, const int64_t* offsets, int64_t n) {
   int64_t maxlen = 0;
   for (int64_t r = 0; r < n; ++r) {
     const int64_t l = offsets[r + 1] - offsets[r];
@@ -1415,34 +1498,104 @@ static int map_small(gf_index* mix, HostLane& L, const char* bases, const int64_
   if (maxlen > GF_MAX_READ_LEN) return fail(GF_ERR_READ_TOO_LONG, "a read exceeds GF_MAX_READ_LEN");
   const int64_t b0 = offsets[0], b1 = offsets[n];
   if (b1 > b0 && !bases) return fail(GF_ERR_ARG, "bases is null");
-  const size_t sz_off = ((size_t)n + 1) * 8, sz_cnt = ((size_t)n + 15) & ~(size_t)15, sz_m = (size_t)n * 32;
-  const size_t sz_b = ((size_t)(b1 - b0) + 64 + 15) & ~(size_t)15;
-  int rc = lane_reserve_pinned(L, sz_off + sz_cnt + sz_m + sz_b + 64);
+  // reads in a gf_host_alloc block are read where they are; anything else is staged in the pinned block
+  const uint8_t* d_src = b1 > b0 ? pinned_device_address(bases + b0, (size_t)(b1 - b0)) : nullptr;
+  const size_t sz_flag = 64, sz_off = (((size_t)n + 1) * 8 + 15) & ~(size_t)15, sz_cnt = ((size_t)n + 15) & ~(size_t)15, sz_m = (size_t)n * 32;
+  const size_t sz_b = d_src ? 0 : (((size_t)(b1 - b0) + 64 + 15) & ~(size_t)15);
+  int rc = zc_reserve(Z, st, sz_flag + sz_off + sz_cnt + sz_m + sz_b + 64);
   if (rc != GF_OK) return rc;
-  int64_t* h_off = (int64_t*)L.pinned;
-  gf_seqmatch* h_m = (gf_seqmatch*)(L.pinned + sz_off);
-  uint8_t* h_cnt = L.pinned + sz_off + sz_m;
-  uint8_t* h_b = L.pinned + sz_off + sz_m + sz_cnt;
+  int64_t* h_off = (int64_t*)(Z.pinned + sz_flag);
+  gf_seqmatch* h_m = (gf_seqmatch*)(Z.pinned + sz_flag + sz_off);
+  uint8_t* h_cnt = Z.pinned + sz_flag + sz_off + sz_m;
+  uint8_t* h_b = Z.pinned + sz_flag + sz_off + sz_m + sz_cnt;
   for (int64_t r = 0; r <= n; ++r) h_off[r] = offsets[r] - b0;
-  if (b1 > b0) memcpy(h_b, bases + b0, (size_t)(b1 - b0));
-  void* dptr = nullptr;
-  GF_HIP(hipHostGetDevicePointer(&dptr, L.pinned, 0));
-  uint8_t* d = (uint8_t*)dptr;
-  const GfTable T = mix->table;
-  const int grid = (int)n;
-  if (maxlen <= 256)
-    hipLaunchKernelGGL((gf_k_map_reads<256, 1, 0>), dim3(grid), dim3(64), 0, L.st, T, (const uint8_t*)(d + (h_b - L.pinned)),
-                       (const int64_t*)d, n, -1, 1, d + (h_cnt - L.pinned), (gf_seqmatch*)(d + sz_off));
-  else if (maxlen <= 1024)
-    hipLaunchKernelGGL((gf_k_map_reads<1024, 1, 0>), dim3(grid), dim3(64), 0, L.st, T, (const uint8_t*)(d + (h_b - L.pinned)),
-                       (const int64_t*)d, n, -1, 1, d + (h_cnt - L.pinned), (gf_seqmatch*)(d + sz_off));
-  else
-    hipLaunchKernelGGL((gf_k_map_reads<4096, 1, 0>), dim3(grid), dim3(64), 0, L.st, T, (const uint8_t*)(d + (h_b - L.pinned)),
-                       (const int64_t*)d, n, -1, 1, d + (h_cnt - L.pinned), (gf_seqmatch*)(d + sz_off));
+  if (!d_src && b1 > b0) memcpy(h_b, bases + b0, (size_t)(b1 - b0));
+  memset(h_cnt, 0, (size_t)n);  // (the kernels write the counts of the reads with segments only: GfTable::done_flag)
+  uint8_t* d = Z.d_pinned;
+  GfTable T = mix->table;
+  static const bool flag_wait = !(getenv("GF_PACK_WAIT") && !strcmp(getenv("GF_PACK_WAIT"), "sync"));  // experiments
+  Z.flag_wait = flag_wait;
+  Z.seq += 1;
+  if (flag_wait) {
+    T.done_ctr = Z.d_done_ctr;
+    T.done_flag = (unsigned int*)d;
+    T.done_seq = Z.seq;
+  }
+  const uint8_t* d_b = d_src ? d_src : (const uint8_t*)(d + (h_b - Z.pinned));
+  const int64_t* d_off = (const int64_t*)(d + sz_flag);
+  uint8_t* d_cnt = d + (h_cnt - Z.pinned);
+  gf_seqmatch* d_m = (gf_seqmatch*)(d + sz_flag + sz_off);
+  if (n <= GF_SMALL_CALL_READS) {
+    const int grid = (int)n;
+    if (maxlen <= 256)
+      hipLaunchKernelGGL((gf_k_map_reads<256, 1, 0>), dim3(grid), dim3(64), 0, st, T, d_b, d_off, n, -1, 1, d_cnt, d_m);
+    else if (maxlen <= 1024)
+      hipLaunchKernelGGL((gf_k_map_reads<1024, 1, 0>), dim3(grid), dim3(64), 0, st, T, d_b, d_off, n, -1, 1, d_cnt, d_m);
+    else
+      hipLaunchKernelGGL((gf_k_map_reads<4096, 1, 0>), dim3(grid), dim3(64), 0, st, T, d_b, d_off, n, -1, 1, d_cnt, d_m);
+  } else {
+    const int top = maxlen <= 256 ? 0 : (maxlen <= 1024 ? 1 : 2);
+    launch_wave_per_read(T, st, mix->n_cus, d_b, d_off, n, top, 1, d_cnt, d_m);
+  }
   GF_HIP(hipGetLastError());
-  GF_HIP(hipStreamSynchronize(L.st));
-  *out_counts = h_cnt;
-  *out_matches = h_m;
+  Z.h_counts = h_cnt;
+  Z.h_matches = h_m;
+  return GF_OK;
+}
+
+// waits for the call queued by zc_submit: on the word the kernel's last block stores — no queue operation, no
+// runtime lock shared with the other callers — and, now and then, by a stream synchronisation that lets the
+// runtime retire the launches; a kernel that never reports (a fault) is found by that synchronisation too
+static int zc_wait(ZeroCopy& Z, hipStream_t st) {
+  bool done = false;
+  const uint32_t* h_flag = (const uint32_t*)Z.pinned;
+  if (Z.flag_wait) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 1;; ++spin) {
+      if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == Z.seq) { done = true; break; }
+      __builtin_ia32_pause();
+      if ((spin & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+    }
+    if (done && ++Z.unsynced >= 64) done = false;
+  }
+  if (!done) {
+    GF_HIP(hipStreamSynchronize(st));
+    Z.unsynced = 0;
+    if (Z.flag_wait && __atomic_load_n(h_flag, __ATOMIC_ACQUIRE) != Z.seq)
+      return fail(GF_ERR_HIP, "a zero-copy call's kernel ended without reporting completion");
+  }
+  return GF_OK;
+}
+
+// the hit records of a finished zero-copy call, put together on the host as gf_k_compact_write does on the device
+static int64_t zc_hits(const ZeroCopy& Z, int64_t n, int64_t read_id_base, gf_hit* out_hits, int64_t cap) {
+  int64_t total = 0;
+  const uint8_t* c8 = Z.h_counts;
+  const gf_seqmatch* m = Z.h_matches;
+  for (int64_t r = 0; r < n; ++r) {
+    const int c = c8[r];
+    if (c != 1 && c != 2) continue;
+    if (total < cap) {
+      gf_hit& h = out_hits[total];
+      h.read_id = read_id_base + r;
+      h.n = c;
+      h.pad = 0;
+      h.m[0] = m[2 * r];
+      if (c > 1) h.m[1] = m[2 * r + 1]; else memset(&h.m[1], 0, sizeof(gf_seqmatch));
+    }
+    total += 1;
+  }
+  return total;
+}
+
+static int map_small(gf_index* mix, HostLane& L, const char* bases, const int64_t* offsets, int64_t n,
+                     const uint8_t** out_counts, const gf_seqmatch** out_matches) {
+  int rc = zc_submit(mix, L.zc, L.st, bases, offsets, n);
+  if (rc != GF_OK) return rc;
+  rc = zc_wait(L.zc, L.st);
+  if (rc != GF_OK) return rc;
+  *out_counts = L.zc.h_counts;
+  *out_matches = L.zc.h_matches;
   return GF_OK;
 }
 
@@ -1459,7 +1612,7 @@ int gf_map_reads(const gf_index* idx, const char* bases, const int64_t* offsets,
   int rc = lease.acquire();
   if (rc != GF_OK) return rc;
   HostLane& L = *lease.lane;
-  if (n <= GF_SMALL_CALL_READS && idx->map_variant == 0) {
+  if (zero_copy_call(idx, n)) {
     const uint8_t* c8 = nullptr;
     const gf_seqmatch* m = nullptr;
     rc = map_small(mix, L, bases, offsets, n, &c8, &m);
@@ -1529,6 +1682,16 @@ int gf_map_reads_hits(const gf_index* idx, const char* bases, const int64_t* off
   int rc = lease.acquire();
   if (rc != GF_OK) return rc;
   HostLane& L = *lease.lane;
+  if (n < 0) return fail(GF_ERR_ARG, "negative n");
+  if (n > 0 && !offsets) return fail(GF_ERR_ARG, "offsets is null");
+  if (zero_copy_call(idx, n)) {  // one pack of the reference's size: one launch, the hit records put together here
+    const uint8_t* c8 = nullptr;
+    const gf_seqmatch* m = nullptr;
+    rc = map_small(mix, L, bases, offsets, n, &c8, &m);
+    if (rc != GF_OK) return rc;
+    *out_n = zc_hits(L.zc, n, read_id_base, out_hits, cap);
+    return GF_OK;
+  }
   HostStage S;
   struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drain{L.st};  // (see gf_map_reads)
   rc = stage_and_map(mix, L, bases, offsets, n, cap, S);
@@ -2242,6 +2405,9 @@ struct gf_stream {
     int64_t* h_total = nullptr;
     bool inflight = false;
     int64_t n = 0;
+    ZeroCopy zc;              // a pack of up to GF_PACK_CALL_READS reads takes the zero-copy route (one launch, no copies)
+    bool zc_call = false;
+    int64_t read_id_base = 0;
   };
   std::vector<Slot> slots;
   int head = 0, tail = 0, live = 0;
@@ -2264,11 +2430,27 @@ void* gf_host_alloc(int64_t bytes) {
     g_err = "hipHostMalloc failed";
     return nullptr;
   }
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess && d) {  // known to the zero-copy calls: they read it in place
+    std::unique_lock<std::shared_mutex> lk(g_pinned_mu);
+    g_pinned.push_back({(const char*)p, (size_t)bytes, (const uint8_t*)d});
+  } else {
+    (void)hipGetLastError();
+  }
   return p;
 }
 
 void gf_host_free(void* p) {
-  if (p) (void)hipHostFree(p);
+  if (!p) return;
+  {
+    std::unique_lock<std::shared_mutex> lk(g_pinned_mu);
+    for (size_t i = 0; i < g_pinned.size(); ++i)
+      if (g_pinned[i].host == (const char*)p) {
+        g_pinned.erase(g_pinned.begin() + (long)i);
+        break;
+      }
+  }
+  (void)hipHostFree(p);
 }
 
 void gf_stream_close(gf_stream* s) {
@@ -2280,6 +2462,7 @@ void gf_stream_close(gf_stream* s) {
     if (sl.arena) (void)hipFree(sl.arena);
     if (sl.h_hits) (void)hipHostFree(sl.h_hits);
     if (sl.h_total) (void)hipHostFree(sl.h_total);
+    sl.zc.release();
     if (sl.st) {
       (void)hipEventDestroy(sl.done);
       // the mapping workspace cached for this stream goes with it
@@ -2344,6 +2527,17 @@ int gf_stream_submit(gf_stream* s, const char* bases, const int64_t* offsets, in
   DeviceGuard guard(s->ix->device);
   gf_stream::Slot& sl = s->slots[(size_t)s->head];
   sl.n = n;
+  sl.zc_call = false;
+  sl.read_id_base = read_id_base;
+  if (zero_copy_call(s->ix, n)) {  // a pack of the reference's size: see ZeroCopy
+    const int rc = zc_submit(s->ix, sl.zc, sl.st, bases, offsets, n);
+    if (rc != GF_OK) return rc;
+    sl.zc_call = true;
+    sl.inflight = true;
+    s->head = (s->head + 1) % s->depth;
+    s->live += 1;
+    return GF_OK;
+  }
   if (n > 0) {
     const size_t lead = (size_t)((uintptr_t)(bases + b0) & 15u);  // keep the span's 16-byte phase
     if (b1 > b0) GF_HIP(hipMemcpyAsync(sl.d_bases + lead, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, sl.st));
@@ -2425,6 +2619,15 @@ int gf_stream_collect(gf_stream* s, gf_hit* out_hits, int64_t cap, int64_t* out_
   if (s->live == 0) return fail(GF_ERR_ARG, "no pack in flight");
   DeviceGuard guard(s->ix->device);
   gf_stream::Slot& sl = s->slots[(size_t)s->tail];
+  if (sl.zc_call) {
+    const int rc = zc_wait(sl.zc, sl.st);
+    if (rc != GF_OK) return rc;
+    *out_n = zc_hits(sl.zc, sl.n, sl.read_id_base, out_hits, cap);
+    sl.inflight = false;
+    s->tail = (s->tail + 1) % s->depth;
+    s->live -= 1;
+    return GF_OK;
+  }
   GF_HIP(hipEventSynchronize(sl.done));
   const int64_t total = sl.n > 0 ? *sl.h_total : 0;
   *out_n = total;
@@ -2564,7 +2767,7 @@ int gf_index_trim(gf_index* idx) {
     for (HostLane* L : idx->lanes) {
       if (L->busy) continue;  // in use by another thread: left alone
       if (L->arena) { GF_HIP(hipFree(L->arena)); L->arena = nullptr; L->arena_bytes = 0; }
-      if (L->pinned) { GF_HIP(hipHostFree(L->pinned)); L->pinned = nullptr; L->pinned_bytes = 0; }
+      L->zc.release();
     }
   }
   // Calls queued on the workspaces' streams may still use them: wait for the whole device, not stream by
@@ -2594,6 +2797,12 @@ int gf_index_trim(gf_index* idx) {
 int gf_set_map_variant(gf_index* idx, int32_t variant) {
   if (!idx || variant < 0 || variant > 2) return fail(GF_ERR_ARG, "bad variant");
   idx->map_variant = variant;
+  return GF_OK;
+}
+
+int gf_set_pack_call_reads(gf_index* idx, int64_t reads) {
+  if (!idx) return fail(GF_ERR_ARG, "null index");
+  idx->pack_call_reads = reads < 0 ? -1 : reads;
   return GF_OK;
 }
 

@@ -133,11 +133,19 @@ class RcclHitExchange:
         self.cap, self.group = int(cap), group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device = torch.device(device)
+        # Every step that can fail on one rank only is followed by an agreement over the torch process group: a rank
+        # that raised alone would leave its peers inside ncclCommInitRank / the first ncclAllGather, waiting for a
+        # collective it never joins.  After an agreement every rank raises, or none does.
         idt = torch.zeros(_lib.GF_COMM_ID_BYTES, dtype=torch.uint8)
+        err = None
         if self.rank == 0:
-            buf = (C.c_uint8 * _lib.GF_COMM_ID_BYTES)()
-            _lib.check(L.gf_comm_unique_id(buf))
-            idt = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+            try:
+                buf = (C.c_uint8 * _lib.GF_COMM_ID_BYTES)()
+                _lib.check(L.gf_comm_unique_id(buf))
+                idt = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+            except Exception as e:  # noqa: BLE001
+                err = e
+        self._agree(err, "gf_comm_unique_id")
         src = dist.get_global_rank(group, 0) if group is not None else 0
         if dist.get_backend(group) == "nccl":   # (the backend moves device tensors only)
             idd = idt.to(self.device)
@@ -147,8 +155,12 @@ class RcclHitExchange:
             dist.broadcast(idt, src=src, group=group)
         idb = (C.c_uint8 * _lib.GF_COMM_ID_BYTES).from_buffer_copy(idt.numpy().tobytes())
         h = C.c_void_p()
-        _lib.check(L.gf_comm_init(idb, self.rank, self.world, self.device.index or 0, C.byref(h)))
-        self._h = h
+        try:
+            _lib.check(L.gf_comm_init(idb, self.rank, self.world, self.device.index or 0, C.byref(h)))
+        except Exception as e:  # noqa: BLE001
+            err = e
+        self._h = h if err is None else None
+        self._agree(err, "gf_comm_init")
         ws = int(L.gf_allgather_workspace_bytes(self.world, self.cap))
         self.side = torch.cuda.Stream(device=self.device)
         self.sets = [dict(ws=torch.empty(ws, dtype=torch.uint8, device=self.device),
@@ -156,6 +168,35 @@ class RcclHitExchange:
                           totals=torch.zeros(2 + self.world, dtype=torch.int64, device=self.device),
                           done=torch.cuda.Event()) for _ in range(depth)]
         self.slot = 0
+
+    def _agree(self, err, what: str) -> None:
+        """all_reduce(MIN) of "this rank is fine" over the torch group; raises on EVERY rank when any rank failed."""
+        on_dev = dist.get_backend(self.group) == "nccl"
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.device if on_dev else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            raise RuntimeError("%s failed on %s: %s" % (what, "this rank (%d)" % self.rank if err is not None else "another rank",
+                                                          err if err is not None else "see its message"))
+
+    def comm_world(self):
+        """(rank, world) as RCCL reports them from inside the communicator (gf_comm_rank)."""
+        r, w = self._C.c_int32(-1), self._C.c_int32(-1)
+        self._lib.check(self._lib.lib().gf_comm_rank(self._h, self._C.byref(r), self._C.byref(w)))
+        return int(r.value), int(w.value)
+
+    def first_exchange(self, hits: torch.Tensor, n_hits: torch.Tensor):
+        """One exchange before anything is timed, with an agreement between queueing it and waiting for it: a rank
+        that could not queue its ncclAllGather is found while the peers' kernels are still waiting for it, and every
+        rank raises instead of hanging in the synchronisation.  Returns (merged, totals)."""
+        err, h = None, None
+        try:
+            h = self.start(hits, n_hits)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        self._agree(err, "the first gf_allgather_hits_device")
+        out = self.finish(h)
+        torch.cuda.synchronize(self.device)
+        return out
 
     def start(self, hits: torch.Tensor, n_hits: torch.Tensor):
         k = self.slot

@@ -463,6 +463,10 @@ class Indexer:
         """0 = flat pipeline (default), 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify."""
         _lib.check(_lib.lib().gf_set_map_variant(self._handle(), int(variant)))
 
+    def set_pack_call_reads(self, reads: int) -> None:
+        """Host-buffer calls of up to `reads` reads take the zero-copy route (gfmatch.h); -1 = default, 0 = batch route."""
+        _lib.check(_lib.lib().gf_set_pack_call_reads(self._handle(), int(reads)))
+
     def last_stage_ms(self):
         """Flat pipeline: ms of its four kernels (seed+verify, filter, buckets, exact kernel)."""
         import ctypes as C

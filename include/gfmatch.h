@@ -479,6 +479,14 @@ int gf_set_profiling(gf_index* idx, int32_t on);
  * every window, 2 = wave-per-read kernel with seed + verify.  All are exact and return identical
  * results; the switch exists for A/B timing and for the tests that check exactly that. */
 int gf_set_map_variant(gf_index* idx, int32_t variant);
+/* Host-buffer calls (gf_map_reads, gf_map_reads_hits, gf_stream_submit) of up to `reads` reads take the zero-copy
+ * route: the pack is staged in pinned memory (or read where it is, when it lies in a gf_host_alloc block), ONE launch
+ * of the exact wave-per-read kernels fetches it over the link and writes the results back, the host waits on a word
+ * the kernel stores — a pack of the reference's size (PACK_SIZE = 1000 pairs, common.rs:23) costs one launch instead
+ * of two copies, seven launches and two copies back.  Larger calls take the batch route (copies + the flat pipeline).
+ * reads < 0 restores the default (8192, or GF_PACK_CALL_READS from the environment); 0 = batch route for every call
+ * beyond 64 reads.  Same results either way (tests/test_boundary_gpu.py). */
+int gf_set_pack_call_reads(gf_index* idx, int64_t reads);
 float gf_last_map_kernel_ms(gf_index* idx);
 
 const char* gf_last_error(void);

@@ -117,3 +117,86 @@ def test_index_free_with_an_open_stream_is_refused(gpu_device, capfd):
     assert ms.collect().shape[0] >= 0    # the index is still there
     ms.close()
     ix.close()
+
+
+def test_pack_route_equals_batch_route(gpu_device, oracle):
+    """A host call of up to 8192 reads (a pack of the reference's size, common.rs:23: 1000 pairs) takes the zero-copy
+    route — the pack in pinned memory, one launch of the wave-per-read kernels, a completion word instead of a stream
+    synchronisation.  Same bytes out as the batch route (copies + flat pipeline) and as the oracle: dense counts,
+    hit records, the streaming entry; pageable sources and sources inside a gf_host_alloc block (read in place, at
+    every byte phase); packs of 1, 65, 2000, 8192 and 8193 reads; a pack with reads of every length class."""
+    from genefuserust_amd import Indexer, synth
+    from genefuserust_amd.stream import MapStream, pinned_empty
+    genes = synth.make_geneset("IDX-T", scale=0.05)
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    ox = oracle.OracleIndexer(genes.seqs)
+    synth.MIXES["TEST"] = (0.2, 0.5, 0.3)
+    n, L = 20_000, 150
+    rb = synth.make_reads(genes, n, read_len=L, mix="TEST", seed=41)
+    bases, offsets = rb.bases.numpy(), rb.offsets.numpy()
+    ocounts, omatches = ox.map_reads_packed(bases, offsets, threads=8)
+
+    def both_routes(fn):
+        out = []
+        for lim in (0, -1):
+            ix.set_pack_call_reads(lim)
+            out.append(fn())
+        ix.set_pack_call_reads(-1)
+        return out
+
+    for phase in (0, 1, 5, 15):
+        hb = pinned_empty(bases.size + 16, np.uint8)
+        hb[phase:phase + bases.size] = bases
+        for src, off in ((bases, offsets), (hb, offsets + phase)):
+            for p0, m in ((0, 1), (3, 65), (100, 2000), (4000, 8192), (9000, 8193)):
+                o = off[p0:p0 + m + 1]
+                (c0, m0), (c1, m1) = both_routes(lambda: ix.map_reads_packed(src, o))
+                assert (c0 == c1).all() and (c0 == ocounts[p0:p0 + m]).all()
+                nz = c0 > 0
+                assert (m0[nz, 0] == m1[nz, 0]).all() and (m1[nz, 0] == omatches[p0:p0 + m][nz, 0]).all()
+                two = c0 == 2
+                assert (m0[two, 1] == m1[two, 1]).all() and (m1[two, 1] == omatches[p0:p0 + m][two, 1]).all()
+                h0, h1 = both_routes(lambda: ix.map_reads_hits(src, o, read_id_base=77 + p0))
+                assert h0.tobytes() == h1.tobytes() and h0.shape[0] == int(nz.sum())
+                # more hits than the caller's capacity: the total is reported, the first `cap` records written
+                if m == 2000:
+                    k0, k1 = both_routes(lambda: ix.map_reads_hits(src, o, read_id_base=77 + p0, cap=10))
+                    assert k0.tobytes() == k1.tobytes() == h0[:10].tobytes()
+        if phase > 1:
+            continue
+        # the streaming entry: packs of 2000 reads (zero-copy slots) against one batch call
+        want = ix.map_reads_hits(bases, offsets, read_id_base=5)
+        for src, off in ((bases, offsets), (hb, offsets + phase)):
+            def run():
+                got = []
+                with MapStream(ix, max_reads=2000, max_bytes=2000 * L, depth=3) as ms:
+                    inflight = 0
+                    for q0 in range(0, n, 2000):
+                        if inflight == ms.depth:
+                            got.append(ms.collect())
+                            inflight -= 1
+                        ms.submit(src, off[q0:q0 + 2001], read_id_base=5 + q0)
+                        inflight += 1
+                    while inflight:
+                        got.append(ms.collect())
+                        inflight -= 1
+                return np.concatenate(got)
+            g0, g1 = both_routes(run)
+            assert g0.tobytes() == g1.tobytes() == want.tobytes()
+    # every length class in one pack (the wave-per-read kernels of the 1024- and 4096-base classes finish the call)
+    rng = np.random.default_rng(9)
+    g0s, g1s = genes.seqs[0], genes.seqs[1]
+    reads = []
+    for k in range(300):  # junction reads: the left part from one gene, the right part from another
+        ln = int(rng.choice([40, 150, 251, 300, 700, 1024, 1500, 4000]))
+        cut = ln // 2 + int(rng.integers(-ln // 8, ln // 8 + 1))
+        p, q = int(rng.integers(0, len(g0s) - ln)), int(rng.integers(0, len(g1s) - ln))
+        reads.append(g0s[p:p + cut] + g1s[q:q + ln - cut])
+    mb, mo = synth.ragged_batch(reads)
+    (c0, m0), (c1, m1) = both_routes(lambda: ix.map_reads_packed(mb, mo))
+    oc, om = ox.map_reads_packed(mb, mo, threads=4)
+    assert (c0 == c1).all() and (c1 == oc).all() and int((oc > 0).sum()) > 100
+    nz = oc > 0
+    assert (m0[nz, 0] == m1[nz, 0]).all() and (m1[nz, 0] == om[nz, 0]).all()
+    ix.close()

@@ -80,14 +80,17 @@ def test_index_content_every_key(branch_index, golden):
     assert not cnt.any()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, "0-pack", 1, 2])
 def test_map_golden_cases(branch_index, golden, variant):
-    """variant 0 = flat pipeline (pack fused into seed+verify), 1 = wave-per-read probe-all,
-    2 = wave-per-read seed+verify."""
-    branch_index.set_map_variant(variant)
+    """variant 0 = flat pipeline (pack fused into seed+verify; the host call's zero-copy route switched off),
+    "0-pack" = the default host call: a pack of this size takes the zero-copy route (one launch of the wave-per-read
+    kernel over pinned memory), 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify."""
+    branch_index.set_pack_call_reads(-1 if variant == "0-pack" else 0)
+    branch_index.set_map_variant(0 if variant == "0-pack" else variant)
     reads = [c["read"].encode() for c in golden["cases"]]
     got = branch_index.map_reads(reads)
     branch_index.set_map_variant(0)
+    branch_index.set_pack_call_reads(-1)
     for c, g in zip(golden["cases"], got):
         flat = [(m.seq_start, m.seq_end, m.start_gp.contig, m.start_gp.position) for m in g]
         assert flat == [tuple(m) for m in c["expect"]], c["label"]
@@ -348,7 +351,7 @@ def test_full_size_properties(gpu_device, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, "0-pack", 2])
 def test_batches_with_gaps_and_mixed_lengths(branch_index, golden, oracle, variant):
     """Reads need not be packed back to back: gaps between reads (so that most of the
     batch lies beyond the packed stream of the flat pipeline), a first offset > 0, every
@@ -363,7 +366,8 @@ def test_batches_with_gaps_and_mixed_lengths(branch_index, golden, oracle, varia
     ox = oracle.OracleIndexer([None if x is None else x.encode() for x in golden["genes"]])
     batch = reads + [long1, long2]
     want = want + [ox.map_read(long1), ox.map_read(long2)]
-    branch_index.set_map_variant(variant)
+    branch_index.set_pack_call_reads(-1 if variant == "0-pack" else 0)  # "0-pack": the zero-copy route of a host call
+    branch_index.set_map_variant(0 if variant == "0-pack" else variant)
     for gap in (0, 7, 400):
         buf = bytearray(rng.integers(65, 91, size=37, dtype=np.uint8).tobytes())  # junk before the first read
         offs = []
@@ -386,6 +390,7 @@ def test_batches_with_gaps_and_mixed_lengths(branch_index, golden, oracle, varia
             got = got[0::2]
         assert got == want, (variant, gap)
     branch_index.set_map_variant(0)
+    branch_index.set_pack_call_reads(-1)
 
 
 def test_device_offsets_with_holes(branch_index, golden):

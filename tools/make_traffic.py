@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/hbm_traffic.json from a tools/profile_gpu.sh output directory (r03: calibrated).
+"""profiles/hbm_traffic.json from a tools/profile_gpu.sh output directory (r03: calibrated; r04: every entry stamped with
+the commit, the hash of the kernel sources and the hash of the library the counters were taken from).
 
     python tools/make_traffic.py gpurun_out/prof_<tag> <key> <source-name>
     python tools/make_traffic.py gpurun_out/prof_<tag> <key> <source-name> --per-step N
@@ -24,10 +25,47 @@ import sys
 from collections import defaultdict
 
 PASS_KERNELS = ("gf_k_seedverify_stream", "gf_k_probe_filter", "gf_k_probe_buckets", "gf_k_map_reads_list")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def build_stamp(out_dir: str) -> dict:
+    """Which build the counters describe.  tools/profile_gpu.sh writes build_stamp.json next to the
+    counter files ON THE GPU BOX (hash of the sources it ran: bench.kernel_source_sha, hash of the libgfmatch.so it
+    loaded); the commit is added here, in the container, where .git is — and refused when the tree's sources are not
+    the ones that were profiled."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    here = {"kernel_src_sha": bench.kernel_source_sha(), "lib_sha": bench.library_sha()}
+    path = os.path.join(out_dir, "build_stamp.json")
+    if not os.path.exists(path):
+        raise SystemExit("%s is missing: profile with tools/profile_gpu.sh (it writes the stamp on the GPU box)" % path)
+    st = json.load(open(path))
+    if st["kernel_src_sha"] != here["kernel_src_sha"]:
+        raise SystemExit("the profile was taken from sources %s, the tree holds %s: profile again" % (st["kernel_src_sha"], here["kernel_src_sha"]))
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "genefuserust_amd/csrc", "include/gfmatch.h"],
+                                    capture_output=True, text=True).stdout.strip())
+    except Exception:
+        # the GPU box has no .git: tools/stamp_head.sh wrote the commit into .git_head before the snapshot was taken
+        head, dirty = None, None
+        try:
+            gh = json.load(open(os.path.join(ROOT, ".git_head")))
+            if gh.get("kernel_src_sha") == st["kernel_src_sha"]:
+                head, dirty = gh.get("git_head"), gh.get("git_dirty_csrc")
+        except Exception:
+            pass
+    return {"git_head": head, "git_dirty_csrc": dirty, "kernel_src_sha": st["kernel_src_sha"], "lib_sha": st["lib_sha"],
+            "bench_args": st.get("bench_args")}
 
 
 def short(kn: str) -> str:
     return kn.split("(")[0].replace("void ", "").strip()
+
+
+ROUND = os.environ.get("GF_ROUND", "r04")
 
 
 def main():
@@ -50,7 +88,7 @@ def main():
             per_kernel[k] = {"launches_per_step": nd[k].get("WRITE_SIZE", 0) / steps, "read_bytes": int(rd), "write_bytes": int(wr)}
             rd_tot += rd
             wr_tot += wr
-        entry = {"round": "r03", "hbm_bytes_per_launch": int(rd_tot + wr_tot), "read_bytes_per_launch": int(rd_tot),
+        entry = {"round": ROUND, **build_stamp(out), "hbm_bytes_per_launch": int(rd_tot + wr_tot), "read_bytes_per_launch": int(rd_tot),
                  "write_bytes_per_launch": int(wr_tot), "steps_profiled": steps, "per_kernel": per_kernel,
                  "unit_of_launch": "one step of the workload (all its kernels)",
                  "correction": "read bytes = 32 B x TCC_EA0_RDREQ_DRAM_32B_sum; write bytes = WRITE_SIZE", "source": source}
@@ -96,7 +134,8 @@ def main():
                         "dram_32B_units_x32_bytes": int(32 * c.get("TCC_EA0_RDREQ_DRAM_32B_sum", 0)),
                         "ea_read_requests": c.get("TCC_EA0_RDREQ_sum"), "tcc_bubble": c.get("TCC_BUBBLE_sum")}
     entry = {
-        "round": "r03",
+        "round": ROUND,
+        **build_stamp(out),
         "hbm_bytes_per_launch": int(rd_tot + wr_tot),
         "read_bytes_per_launch": int(rd_tot), "write_bytes_per_launch": int(wr_tot),
         "passes_profiled": nd[main_sv].get("WRITE_SIZE"),

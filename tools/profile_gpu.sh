@@ -14,6 +14,15 @@ cd /tmp && export TMPDIR=/tmp
 # PMC_SETS: "all" (default), "traffic" (FETCH/WRITE/TCC only) or "min" (three passes: bytes and L2 hits / misses)
 BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --profile-mode ${BENCH_ARGS:-}"
 PMC_SETS=${PMC_SETS:-all}
+# which build these counters describe: hashes of the sources and of the library on THIS box (tools/make_traffic.py adds the commit)
+python3 - "$OUT" "${BENCH_ARGS:-}" <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+json.dump({"kernel_src_sha": bench.kernel_source_sha(), "lib_sha": bench.library_sha(), "bench_args": sys.argv[2]},
+          open(sys.argv[1] + "/build_stamp.json", "w"))
+PY
 echo "== kernel trace ==" 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.log 2>&1 || { echo trace failed; tail -20 $OUT/trace_bench.log; exit 1; }
 # (r03: TCC_BUBBLE = the 128-byte read requests FETCH_SIZE's gfx950 formula relies on; the _DRAM_32B counter
