@@ -508,6 +508,11 @@ def main() -> None:
             result["packed_input"] = packed_ms
         if fixed_ms:
             result["fixed_length_input"] = fixed_ms
+        if world == 1 and not args.no_stress and args.config == 1 and not (args.shape or args.repeat_frac is not None or args.low_complexity):
+            try:
+                result["stress"] = stress_rows(args, cfg, local_rank, dev, L, seed)
+            except Exception as e:  # noqa: BLE001 — reported extras, never the value
+                result["stress"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_pack_sweep:
             try:
                 result["pack_sweep"] = pack_sweep(genes, reads, n, L)
@@ -644,6 +649,50 @@ def cpu_baseline(ox, reads, n, L, cores, cpu_seconds):
                   "%d threads pulling 1000-read packs); %.1f s" % (ns, cores, dt),
         "value_4_threads": t4,
     }
+
+
+def stress_rows(args, cfg, local_rank, dev, L, seed):
+    """The headline's pass on gene sets and read mixes that are harder than SURVEY.md 8(d)'s defaults (2 % repeats, PANEL),
+    outside the timed region, 8 M reads each: human introns are 40-50 % interspersed repeats, the default genes 2 %.
+    Kernel-only rates like `roofline.kernel_reads_per_s`; the full-size rows are profiles/r04_stress_*.json."""
+    import torch
+    from genefuserust_amd import Indexer, synth
+    pairs = 4_000_000
+    rows = {}
+    specs = [("repeat10", dict(shape=cfg["shape"], gene_kw=dict(repeat_frac=0.10), mix="PANEL")),
+             ("repeat30", dict(shape=cfg["shape"], gene_kw=dict(repeat_frac=0.30), mix="PANEL")),
+             ("lowcomplexity5", dict(shape=cfg["shape"], gene_kw=dict(low_complexity_frac=0.05), mix="PANEL")),
+             ("wgs_mix", dict(shape=cfg["shape"], gene_kw={}, mix="WGS")),
+             ("idx_t", dict(shape="IDX-T", gene_kw={}, mix="PANEL"))]
+    stream = torch.cuda.current_stream(dev)
+    for name, sp in specs:
+        genes = synth.make_geneset(sp["shape"], **sp["gene_kw"])
+        ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags, device=local_rank)
+        ix.make_index()
+        reads = synth.make_pair_reads(genes, pairs, read_len=L, mix=sp["mix"], seed=seed + 77, device=str(dev))
+        n = 2 * pairs
+        counts = torch.empty(n, dtype=torch.uint8, device=dev)
+        matches = torch.empty((n, 2, 4), dtype=torch.int32, device=dev)
+        ix.map_reads_device(reads.bases, reads.offsets, L, counts, matches)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        e0.record(stream)
+        for _ in range(reps):
+            ix.map_reads_device(reads.bases, reads.offsets, L, counts, matches)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        info = ix.info()
+        rows[name + "_reads_per_s"] = n / (ms * 1e-3)
+        rows[name] = {"map_ms": round(ms, 4), "reads": n, "index_keys": info["n_keys"], "high_keys": info["n_high_keys"],
+                      "dupe_keys": info["n_dupe_keys"], "reads_with_segments": int(((counts > 0) & (counts < 255)).sum().item()),
+                      "shape": sp["shape"], "mix": sp["mix"], "gene_synthesis": sp["gene_kw"]}
+        ix.close()
+        del reads, counts, matches, genes
+    rows["what"] = ("kernel-only reads/s of gf_map_reads_device on 8 M reads (4 M PANEL/WGS pairs), outside the timed region; "
+                    "repeatNN = NN % of every gene overwritten by copies of a 20-element family of 300-bp repeats "
+                    "(headline: 2 %), lowcomplexity5 = 5 % poly-A / tandem-repeat stretches")
+    return rows
 
 
 def pack_sweep(genes, reads, n, L):

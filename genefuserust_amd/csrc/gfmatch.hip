@@ -640,7 +640,10 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   static uint8_t* stage = nullptr;
   static size_t stage_bytes = 0;
   std::unique_lock<std::mutex> stage_lock(stage_mu);
-  struct StageDrain { ~StageDrain() { (void)hipDeviceSynchronize(); } } stage_drain;  // copies out of the block are done before the next build may write it
+  // copies out of the block are done before the next build may write it: on the early exits by this guard, on the
+  // way through by the synchronous copy of the statistics below, after which the block is handed on (it
+  // used to stay locked until the build returned, so builds on different devices or threads took turns for all of it)
+  struct StageDrain { bool armed = true; ~StageDrain() { if (armed) (void)hipDeviceSynchronize(); } } stage_drain;
   const size_t meta_words = ((size_t)n_genes + 1) + 3 * lin_base.size();
   const size_t need_stage = cat_bytes + meta_words * sizeof(uint32_t) + 64;
   if (stage_bytes < need_stage) {
@@ -837,6 +840,14 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   hipLaunchKernelGGL(gf_k_classify_assign, dim3(std::min(sweep_grid, ix->n_cus * 4)), dim3(256), 0, 0, ix->d_slots, nslots, d_stats.p);
   GF_HIP(hipGetLastError());
   GF_HIP(hipMemcpy(stats, d_stats.p, sizeof stats, hipMemcpyDeviceToHost));
+  // Everything queued before that copy is done — the kernels and copies that read the staging block among it: the
+  // block (and with it the host pool, one job at a time) goes to the next build while this one finishes its lists.
+  if (pool_wait.pool) {
+    pool_wait.pool->wait();
+    pool_wait.pool = nullptr;
+  }
+  stage_drain.armed = false;
+  stage_lock.unlock();
   lap(two_pass ? "strands, count pass, list assignment + statistics" : "strands, insert pass (sites, flags, filter), list assignment + statistics");
   const uint64_t dupes_extent = stats[6];  // (>= stats[5], the sites in the lists: granules end unused)
   if (dupes_extent > dupes_cap)
@@ -2540,6 +2551,7 @@ int gf_stream_submit(gf_stream* s, const char* bases, const int64_t* offsets, in
   }
   if (n > 0) {
     const size_t lead = (size_t)((uintptr_t)(bases + b0) & 15u);  // keep the span's 16-byte phase
+    struct Drain { hipStream_t st; bool armed = true; ~Drain() { if (armed) (void)hipStreamSynchronize(st); } } drain{sl.st};  // (see gf_stream_submit_packed)
     if (b1 > b0) GF_HIP(hipMemcpyAsync(sl.d_bases + lead, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, sl.st));
     GF_HIP(hipMemcpyAsync(sl.d_off, offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, sl.st));
     int rc = gf_map_reads_device(s->ix, sl.d_bases + lead - b0, sl.d_off, n, (int32_t)std::max<int64_t>(maxlen, 1),
@@ -2551,6 +2563,7 @@ int gf_stream_submit(gf_stream* s, const char* bases, const int64_t* offsets, in
     GF_HIP(hipMemcpyAsync(sl.h_total, sl.d_total, 8, hipMemcpyDeviceToHost, sl.st));
     GF_HIP(hipMemcpyAsync(sl.h_hits, sl.d_hits, (size_t)std::min(n, s->pin_cap) * sizeof(gf_hit), hipMemcpyDeviceToHost,
                           sl.st));
+    drain.armed = false;
   } else {
     *sl.h_total = 0;
   }
@@ -2581,17 +2594,20 @@ int gf_stream_submit_packed(gf_stream* s, const uint32_t* pk, const uint16_t* iv
   gf_stream::Slot& sl = s->slots[(size_t)s->head];
   sl.n = n;
   if (n > 0) {
-    // chunks c0 .. c1-1 cover the pack's bases (+1: the kernels' staging reads one chunk past a tile's last);
-    // the slot's base area (max_bytes + 64 bytes) holds them: 6 bytes per chunk of 16 bases
-    const int64_t c0 = b0 >> 4, c1 = ((b1 + 15) >> 4) + 1, nc = c1 - c0;
+    // chunks c0 .. c1-1 cover the pack's bases and the four chunks past them that every packed buffer carries
+    // (gf_packed_chunks: the kernels' staging reads past a tile's last chunk; the host's arrays hold them — the next
+    // reads' chunks inside a buffer, gf_pack_bases_host's padding at its end); the slot's base area
+    // (max_bytes + 64 bytes) holds them: 6 bytes per chunk of 16 bases
+    const int64_t c0 = b0 >> 4, c1 = ((b1 + 15) >> 4) + 4, nc = c1 - c0;
     uint32_t* d_pk = (uint32_t*)sl.d_bases;
     uint16_t* d_iv = (uint16_t*)(sl.d_bases + (((size_t)nc * 4 + 15) & ~(size_t)15));
     if ((((size_t)nc * 4 + 15) & ~(size_t)15) + (size_t)nc * 2 > (size_t)s->max_bytes + 64)
       return fail(GF_ERR_CAPACITY, "pack has more bases than the stream was opened for");
-    GF_HIP(hipMemcpyAsync(d_pk, pk + c0, (size_t)(nc - 1) * 4, hipMemcpyHostToDevice, sl.st));
-    GF_HIP(hipMemcpyAsync(d_iv, iv + c0, (size_t)(nc - 1) * 2, hipMemcpyHostToDevice, sl.st));
-    GF_HIP(hipMemsetAsync(d_pk + (nc - 1), 0, 4, sl.st));       // the chunk past the end: nothing, all bad
-    GF_HIP(hipMemsetAsync(d_iv + (nc - 1), 0xFF, 2, sl.st));
+    // whatever way this call ends, the copies out of the caller's pinned pk / iv / offsets are not left pending on
+    // an error return (the caller may reuse them at once: the pack never became a slot in flight)
+    struct Drain { hipStream_t st; bool armed = true; ~Drain() { if (armed) (void)hipStreamSynchronize(st); } } drain{sl.st};
+    GF_HIP(hipMemcpyAsync(d_pk, pk + c0, (size_t)nc * 4, hipMemcpyHostToDevice, sl.st));
+    GF_HIP(hipMemcpyAsync(d_iv, iv + c0, (size_t)nc * 2, hipMemcpyHostToDevice, sl.st));
     GF_HIP(hipMemcpyAsync(sl.d_off, offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, sl.st));
     // the device arrays start at chunk c0 of the host's stream: shift the pointers, the offsets stay as they are
     int rc = gf_map_reads_packed_device(s->ix, d_pk - c0, d_iv - c0, sl.d_off, n, (int32_t)std::max<int64_t>(maxlen, 1),
@@ -2603,6 +2619,7 @@ int gf_stream_submit_packed(gf_stream* s, const uint32_t* pk, const uint16_t* iv
     GF_HIP(hipMemcpyAsync(sl.h_total, sl.d_total, 8, hipMemcpyDeviceToHost, sl.st));
     GF_HIP(hipMemcpyAsync(sl.h_hits, sl.d_hits, (size_t)std::min(n, s->pin_cap) * sizeof(gf_hit), hipMemcpyDeviceToHost,
                           sl.st));
+    drain.armed = false;  // the pack is in flight: gf_stream_collect waits for it
   } else {
     *sl.h_total = 0;
   }
@@ -2739,6 +2756,13 @@ static int exch_grid(int64_t records) { return (int)std::max<int64_t>(1, std::mi
 int gf_pack_gathered_hits_device(const void* d_recv, int32_t world, int64_t cap, void* d_merged, void* d_totals, void* stream) {
   if (world < 1 || world > GF_EXCH_MAX_WORLD || cap < 0) return fail(GF_ERR_ARG, "bad world (1..64) or cap");
   if (!d_recv || !d_totals || (cap > 0 && !d_merged)) return fail(GF_ERR_ARG, "null device pointer");
+  // standalone callers have no index or communicator to name the device: it is the one the receive buffer lives on
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, d_recv) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(GF_ERR_ARG, "d_recv is not a device pointer");
+  }
+  DeviceGuard guard(attr.device);
   hipLaunchKernelGGL(gf_k_exch_pack, dim3(exch_grid((int64_t)world * cap)), dim3(256), 0, (hipStream_t)stream,
                      (const gf_hit*)d_recv, world, cap, (gf_hit*)d_merged, (int64_t*)d_totals);
   GF_HIP(hipGetLastError());

@@ -43,3 +43,38 @@ def test_plain_gpus_2_prints_one_line_in_rehearsal_mode(gpu_device):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["parity"]["bit_exact"]
     assert j["h2d_inclusive"]["reads_per_s_all_ranks"] > 0 and len(j["h2d_inclusive"]["per_rank_reads_per_s"]) == 2
+
+
+def _one_line(out):
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_rehearsal_four_ranks_configs_1_3_4(gpu_device):
+    """The N > 1 code paths of configs 1, 3 and 4 with FOUR ranks on the box's one GPU (gloo exchange; sized down).  Four,
+    not eight: a GPU box admits at most 6 processes on its card at once, and the test runner and the launcher's agent
+    hold it too (six ranks were killed by the box's process guard, r04) — the 8-rank plan and its group exchange are
+    covered on the CPU (tests/test_dist.py::test_multi_csv_groups_of_four_ranks_gloo).  Never a measurement: the first
+    real multi-GPU run is the driver's (fusion_scan.rs:103-116 is the split being rehearsed)."""
+    common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-h2d", "--no-pack-sweep", "--no-stress"]
+    env = _env(GF_BENCH_REHEARSAL="1")
+    # config 1: weak scaling, every rank its own shard
+    j = _one_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--pairs", "60000"] + common,
+                                 capture_output=True, text=True, timeout=900, env=env))
+    assert j["n_gpus"] == 4 and j["scaling"] == "weak" and j["config"]["ranks_seen"] == 4 and j["parity"]["bit_exact"]
+    assert j["config"]["reads_per_gpu_per_step"] == 120000 and j["config"]["hits_per_step"] > 0
+    # config 3: strong scaling, one batch sharded over the ranks
+    j = _one_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "3", "--pairs", "200000"] + common,
+                                 capture_output=True, text=True, timeout=900, env=env))
+    assert j["n_gpus"] == 4 and j["scaling"] == "strong" and j["config"]["reads_per_gpu_per_step"] == 100000
+    assert j["parity"]["bit_exact"] and j["config"]["ranks_seen"] == 4
+    # config 4: 5 CSVs over 4 ranks (rank 0 owns two), then 2 CSVs over 4 ranks (groups of two, one exchange per CSV)
+    for n_csv in (5, 2):
+        j = _one_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "4", "--pairs", "60000",
+                                      "--n-csv", str(n_csv), "--scale", "0.05"] + common,
+                                     capture_output=True, text=True, timeout=900, env=env))
+        assert j["n_gpus"] == 4 and j["config"]["n_csv"] == n_csv
+        assert all(v["bit_exact"] for v in j["parity"].values())

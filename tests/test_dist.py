@@ -188,3 +188,71 @@ def test_rccl_exchange_through_the_c_abi_one_rank(gpu_device):
         ex.close()
     finally:
         dist.destroy_process_group()
+
+
+def _csv_hits(csv, lo, hi, cap):
+    """Ordered hit records of reads lo..hi-1 against CSV `csv`: another rule per CSV."""
+    ids = [r for r in range(lo, hi) if (r + 3 * csv) % (5 + 2 * csv) == 1]
+    h = torch.zeros((cap, HIT_WORDS), dtype=torch.int64)
+    for k, r in enumerate(ids):
+        h[k, 0] = r
+        h[k, 1] = 1 + ((r + csv) % 2)
+        h[k, 3] = 1000 * csv + r
+    return h, torch.tensor([len(ids)], dtype=torch.int64)
+
+
+def _group_worker(rank, world, port, n_csv, n, q):
+    from genefuserust_amd.multi_csv import plan_multi_csv
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        inner = world // n_csv
+        groups = {}
+        for k in range(n_csv):   # created collectively, in the same order on every rank (bench.py::bench_multi_csv)
+            g = tuple(range(k * inner, (k + 1) * inner))
+            groups[g] = dist.new_group(list(g))
+        jobs = plan_multi_csv(n_csv, n, rank, world)
+        assert len(jobs) == (1 if rank < n_csv * inner else 0)
+        for j in jobs:
+            assert rank in j.group and len(j.group) == inner and j.group in groups
+            hits, n_hits = _csv_hits(j.csv, j.lo, j.hi, cap=j.hi - j.lo + 1)
+            merged = allgather_hits(hits, n_hits, group=groups[j.group])
+            ex = HitExchange(cap=(n // inner) // 2 + 8, device="cpu", group=groups[j.group])
+            ha = ex.start(hits, n_hits)
+            hb = ex.start(hits[:3], torch.tensor([min(3, int(n_hits))], dtype=torch.int64))   # a second batch in flight
+            m1, t1, o1 = ex.finish(ha)
+            m2, t2, o2 = ex.finish(hb)
+            assert not bool(o1) and not bool(o2)
+            q.put((rank, j.csv, j.lo, j.hi, merged.numpy().copy(), m1[: int(t1)].numpy().copy(), int(t2)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multi_csv_groups_of_four_ranks_gloo():
+    """BASELINE configs[4] with fewer CSVs than ranks — 8 ranks, 2 CSVs: plan_multi_csv forms two groups of four
+    (fusion_scan.rs:103-110 with ranks for threads), each rank maps a quarter of the reads against its group's CSV, the
+    group merges its lists with the path's one exchange INSIDE the group (both forms: allgather_hits and HitExchange
+    with two batches in flight).  Every rank of a group ends with the list one process produces for that CSV."""
+    world, n_csv, n = 8, 2, 4001
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, n_csv, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(g[0] for g in got) == list(range(world))
+    for rank, csv, lo, hi, merged, ex_merged, t2 in got:
+        assert csv == rank // 4
+        pos = rank % 4
+        assert (lo, hi) == shard_range(n, pos, 4)
+        want, cnt = _csv_hits(csv, 0, n, cap=n)
+        want = want[: int(cnt)].numpy()
+        assert np.array_equal(merged, want) and np.array_equal(ex_merged, want)
+        assert (np.diff(merged[:, 0]) > 0).all()
+        # the second batch: every rank of the group sent its first min(3, count) records
+        assert t2 == sum(min(3, int(_csv_hits(csv, *shard_range(n, p, 4), cap=n)[1])) for p in range(4))
