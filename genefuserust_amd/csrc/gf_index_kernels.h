@@ -846,3 +846,15 @@ __global__ void gf_k_sort_dupes(const uint64_t* slots, uint64_t nslots, uint32_t
     }
   }
 }
+
+// The strands + flags array once more in overlapping tiles (GfTable::gdt): tile t = pairs 6t .. 6t+15 (zero beyond the
+// array's end).  One thread per pair of a tile; runs when the flags are final (after the side list).
+#define GF_GDT_STRIDE 6u
+__global__ __launch_bounds__(256) void gf_k_gdu_tiles(const uint2* __restrict__ gdu, uint32_t gd_words, uint2* __restrict__ gdt,
+                                                      uint32_t n_tiles) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // pair i & 15 of tile i >> 4
+  if ((i >> 4) >= n_tiles) return;
+  const uint32_t p = GF_GDT_STRIDE * (i >> 4) + (i & 15u);
+  gdt[i] = p < gd_words ? gdu[p] : make_uint2(0u, 0u);
+}
+

@@ -238,6 +238,106 @@ __device__ __forceinline__ uint32_t gf_window_mask(int nwin, int k) {
 #ifndef GF_SVS_WAVES_PER_SIMD
 #define GF_SVS_WAVES_PER_SIMD 4  // (four blocks per CU run anyway, see launch_flat: the registers of six are not needed)
 #endif
+// ---- the background reads' filter rounds, by queue (r04) ----
+// r04 measured what binds seed+verify: nine more vector instructions per filter look-up (no memory access) cost 14 % of
+// its time — the kernel is bound by instruction issue, and two thirds of its instructions were the two filter rounds
+// and their vote bound, executed by every wave for the 40 % of its lanes that hold a background read (round 0) and the
+// 24 % that outlive it (round 1).  So the rounds no longer run where a read happens to sit: a read without a candidate
+// diagonal is written — its packed words, its standing windows, the round it is due — to a queue in its wave's LDS
+// (the layout of a list entry, 64 bytes), and whenever 64 records wait, the wave runs ONE round for 64 of them, every
+// lane busy, each on its own record's round.  A record that outlives round 0 goes back into the queue for round 1;
+// one that outlives round 1 goes to the list as before; the others are decided ([]).  Same decisions, read by read.
+#define GF_FQ_CAP 96  // records per wave: a tile adds at most 64 to at most 63 waiting (more: passes run first)
+
+template <int PW>
+__device__ __forceinline__ int gf_filter_queue_pass(const GfTable& T, gf_u32x4* s_q, int q_len, int lane,
+                                                    uint8_t* __restrict__ counts, GfPipeEntryW<PW>* my_list,
+                                                    unsigned int* s_cnt) {
+  static_assert(PW == 10, "the queue holds the 64-byte entries of reads of up to 160 bases");
+  constexpr int NT = GfPipeEntryW<PW>::NT;
+  const int m = q_len < 64 ? q_len : 64;
+  const int base = q_len - m;  // the last m records: what a pass leaves behind goes back to the same place
+  const bool act = lane < m;
+  uint32_t w[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) w[j] = 0;
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const gf_u32x4 q = s_q[(base + lane) * 4 + j];
+      w[4 * j] = q.x; w[4 * j + 1] = q.y; w[4 * j + 2] = q.z; w[4 * j + 3] = q.w;
+    }
+  }
+  gf_wave_lds_sync();  // every lane holds its record: the places may be written again
+  const __amdgpu_buffer_rsrc_t filter_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)T.bloom, 0, (int)(T.bloom_words * 4u), 0x00020000);
+  const uint32_t filter_bytes = T.bloom_words * 4u;
+  const uint32_t rnd = w[1];  // 0: the even pairs of windows are due, 1: the odd pairs
+  bool alive = false;
+  if (act) {
+    uint32_t wlo = w[2 + NT];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const uint32_t whi = j + 1 < PW ? w[2 + NT + j + 1] : 0u;
+      const uint32_t byte = (w[2 + (j >> 2)] >> (8 * (j & 3))) & 0xFFu;  // this word's 8 windows
+      uint32_t word[2], bits[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // pair u = 2t + rnd of the word: windows 8j+2u, 8j+2u+1 share the 14-mer at bases 16j + 4u+2 ..
+        const uint32_t s14 = __builtin_amdgcn_alignbit(whi, wlo, 16u * (uint32_t)t + 8u * rnd + 4u) & 0x0FFFFFFFu;
+        const uint32_t h2 = GF_BLOOM_HASH((s14));
+        bits[t] = GF_BLOOM_BITS(h2);
+        const uint32_t nb = (byte & (3u << (4 * t + 2 * rnd))) ? filter_bytes : 0u;  // nobody to ask for: word 0
+        word[t] = __builtin_amdgcn_raw_buffer_load_b32(filter_rsrc, __umulhi(h2, nb) & ~3u, 0, GF_FILTER_AUX);
+      }
+      uint32_t fail2 = 0;  // bit 2u: the filter rules out pair u's 14-mer
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t d = bits[t] & ~word[t];
+        uint32_t f;
+        asm("v_min_u32 %0, %1, 1" : "=v"(f) : "v"(d));
+        fail2 |= f << (4 * t);
+      }
+      fail2 <<= 2 * rnd;
+      w[2 + (j >> 2)] &= ~((fail2 | (fail2 << 1)) << (8 * (j & 3)));
+      wlo = whi;
+    }
+    uint32_t x[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) x[k] = (w[2 + k] | (w[2 + k] >> 1)) & 0x55555555u;
+    alive = gf_vote_bound_pairs<4 * PW - 3>(x) >= GF_MAJOR_KEYS / 2;
+  }
+  if (act && !alive) counts[w[0]] = 0;  // proved unable to reach the gate (indexer.rs:353-360)
+  // round 0 outlived: back into the queue, due for round 1
+  const bool again = act && alive && rnd == 0u;
+  const uint64_t am = __ballot(again);
+  if (again) {
+    const int slot = base + gf_lanes_below(am);
+    w[1] = 1u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gf_u32x4 q;
+      q.x = w[4 * j]; q.y = w[4 * j + 1]; q.z = w[4 * j + 2]; q.w = w[4 * j + 3];
+      s_q[slot * 4 + j] = q;
+    }
+  }
+  // both rounds outlived: an undecided read whose listed windows have been through the filter
+  const bool emit = act && alive && rnd != 0u;
+  const unsigned int slot_b = gf_wave_append_lds(emit, s_cnt);
+  if (emit) {
+    w[1] = GF_ENTRY_FILTERED;
+    gf_u32x4* dst = (gf_u32x4*)(my_list + slot_b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gf_u32x4 q;
+      q.x = w[4 * j]; q.y = w[4 * j + 1]; q.z = w[4 * j + 2]; q.w = w[4 * j + 3];
+      dst[j] = q;
+    }
+  }
+  gf_wave_lds_sync();
+  return base + __popcll(am);
+}
+
 // PACKED: the reads arrive as the 2-bit + bad-bit form of the whole `bases` stream (gf_pack_bases_device:
 // word c of g_pk / g_iv = bases 16c .. 16c+15, `offsets` still count bases) — a tile is then copied,
 // 6 bytes per 16 bases instead of 16, and nothing is converted.
@@ -260,6 +360,12 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
   constexpr int NT = GfPipeEntryW<PW>::NT;          // words of one bit per stride-2 window
   __shared__ __attribute__((aligned(16))) uint32_t s_pk_all[4][PK_WORDS];
   __shared__ uint32_t s_iv_all[4][IV_WORDS];
+#ifndef GF_SV_INLINE_ROUNDS
+  constexpr bool QUEUED = PW == 10;  // the filter rounds of reads without a candidate diagonal go by queue (above)
+#else
+  constexpr bool QUEUED = false;     // (A/B build: the rounds inline, as in r03)
+#endif
+  __shared__ gf_u32x4 s_q_all[QUEUED ? 4 : 1][QUEUED ? GF_FQ_CAP * 4 : 1];
   __shared__ unsigned int s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
@@ -267,6 +373,8 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint32_t* s_pk = s_pk_all[wave];
   uint32_t* s_iv = s_iv_all[wave];
+  gf_u32x4* s_q = s_q_all[QUEUED ? wave : 0];
+  int q_len = 0;  // records waiting in this wave's queue (wave-uniform)
   const int64_t r_lo = (int64_t)blockIdx.x * per_block;
   int64_t n_lim = n;
   if (T.n_dev) {  // (the reads beyond the device-side count are empty slots nobody asks about)
@@ -352,6 +460,10 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       __builtin_amdgcn_sched_barrier(0);
       const bool in_range = lane < nfit;
       bool undecided = false, long1k = false, long4k = false;
+      bool queued = false;  // a read without a candidate diagonal, on its way to the wave's filter queue
+      uint32_t pp_q[NT];    // ... and its standing windows
+#pragma unroll
+      for (int k = 0; k < NT; ++k) pp_q[k] = 0;
       uint32_t e_v1v2 = 0, e_todo[NT];
 #pragma unroll
       for (int k = 0; k < NT; ++k) e_todo[k] = 0;
@@ -515,6 +627,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // reach the gate.  Survivors carry the windows still standing and a flag that tells
           // gf_k_probe_filter to pass them on as they are.
           bool filt_done = false, filt_dead = false;
+#ifdef GF_ABLATE_EXTRA_VALU
+          uint32_t ablate_sink = 0;
+#endif
           const __amdgpu_buffer_rsrc_t filter_rsrc =
               __builtin_amdgcn_make_buffer_rsrc((void*)T.bloom, 0, (int)(T.bloom_words * 4u), 0x00020000);
           const uint32_t filter_bytes = T.bloom_words * 4u;
@@ -531,7 +646,20 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // bound does not stop (three false positives or more, or windows that really are in the table) asks
           // the odd pairs in round 1 and meets the bound again with everything known.  13 + 4 look-ups instead of
           // 28 + 4 for a background read, and these look-ups are the kernel's bound.
-          if (PW == 10 && K == GF_NONE_LIN && T.bloom_in_l2 == 2) {
+          if (QUEUED && K == GF_NONE_LIN && T.bloom_in_l2 == 2) {
+            // by queue (gf_filter_queue_pass): the standing windows go along; a read with fewer than 20 clean
+            // windows left cannot reach the gate whatever the filter says
+            filt_done = true;
+            if (nvalid < GF_MAJOR_KEYS / 2) {
+              filt_dead = true;
+            } else {
+              queued = true;
+#pragma unroll
+              for (int k = 0; k < NT; ++k) pp_q[k] = cwb[k];
+              pp_q[0] |= khigh[0];  // (in the table: they stand, as far as the bound's runs are concerned)
+              pp_q[1] |= khigh[1];
+            }
+          } else if (PW == 10 && K == GF_NONE_LIN && T.bloom_in_l2 == 2) {
             filt_done = true;
 #pragma unroll
             for (int k = 0; k < NT; ++k) pp[k] = cwb[k];
@@ -552,6 +680,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
                     // pair u = 2t + rnd of the word: windows 8j+2u, 8j+2u+1 share the 14-mer at bases 16j + 4u+2 ..
                     const uint32_t s14 = __builtin_amdgcn_alignbit(whi, wlo, 16u * (uint32_t)t + 8u * rnd + 4u) & 0x0FFFFFFFu;
                     const uint32_t h2 = GF_BLOOM_HASH((s14));
+#ifdef GF_ABLATE_EXTRA_VALU  // timing only: one more canonical form per look-up (8 vector instructions, no memory access)
+                    ablate_sink ^= gf_canon14(s14 ^ 0x05A5A5A5u);
+#endif
                     bits[t] = GF_BLOOM_BITS(h2);
                     const uint32_t nb = (byte & (3u << (4 * t + 2 * rnd))) ? filter_bytes : 0u;  // nobody to ask for: word 0
                     word[t] = __builtin_amdgcn_raw_buffer_load_b32(filter_rsrc, __umulhi(h2, nb) & ~3u, 0, GF_FILTER_AUX);
@@ -656,6 +787,10 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           for (int k = 0; k < NT; ++k) vmb[k] = 0;
           if (K != GF_NONE_LIN) {
             const uint2* gp = (const uint2*)T.gdu + (K >> 4);  // (gd word, ub2 word) pairs
+            if (PW == 10 && T.gdt != nullptr) {  // the tiled copy: these 11 pairs in one cache line (gf_table.h: gdt)
+              const uint32_t p = K >> 4, t = __umulhi(p, 0xAAAAAAABu) >> 2;  // t = p / 6
+              gp = (const uint2*)T.gdt + 16u * t + (p - 6u * t);
+            }
             const uint32_t bo = 2u * (K & 15u);
             uint2 gw[PW + 1];
 #pragma unroll
@@ -683,6 +818,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             }
           }
           int v1 = 0;
+#ifdef GF_ABLATE_EXTRA_VALU
+          if (ablate_sink == 0x12345u) v1 = 1;
+#endif
 #pragma unroll
           for (int k = 0; k < NT; ++k) {
             vmb[k] &= cwb[k];  // windows that run past the end of the read compared garbage
@@ -690,7 +828,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           }
           // every other diagonal gets at most one vote per window that can still vote
           const int open = nvalid - v1;
-          if (v1 + open < GF_MAJOR_KEYS / 2 || open < GF_MINOR_KEYS / 2 || filt_dead) {
+          if (queued) {
+            // (decided by the queue's passes)
+          } else if (v1 + open < GF_MAJOR_KEYS / 2 || open < GF_MINOR_KEYS / 2 || filt_dead) {
             counts[r] = 0;
           } else if (filt_done) {
             undecided = true;
@@ -710,6 +850,31 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (QUEUED) {
+        const uint64_t qm = __ballot(queued);
+        if (qm) {
+          const int n_new = __popcll(qm);
+          while (q_len + n_new > GF_FQ_CAP) q_len = gf_filter_queue_pass<PW>(T, s_q, q_len, lane, counts, my_list, &s_cnt);
+          if (queued) {  // the record = the read's list entry, its second word the round it is due
+            const int slot = q_len + gf_lanes_below(qm);
+            uint32_t ew[16];
+            ew[0] = (uint32_t)r;
+            ew[1] = 0u;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) ew[2 + k] = pp_q[k];
+#pragma unroll
+            for (int j = 0; j < PW; ++j) ew[2 + NT + j] = gf_cut_pk(s_pk, w0, sh, j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              gf_u32x4 q;
+              q.x = ew[4 * j]; q.y = ew[4 * j + 1]; q.z = ew[4 * j + 2]; q.w = ew[4 * j + 3];
+              s_q[slot * 4 + j] = q;
+            }
+          }
+          q_len += n_new;
+          gf_wave_lds_sync();
+        }
+      }
       const unsigned int slot_b = gf_wave_append_lds(undecided, &s_cnt);
 #ifdef GF_ENTRY_DIRECT_STORE
       constexpr bool direct_store = true;
@@ -761,6 +926,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
         }
       }
       }
+      if constexpr (QUEUED) {
+        while (q_len >= 64) q_len = gf_filter_queue_pass<PW>(T, s_q, q_len, lane, counts, my_list, &s_cnt);
+      }
       if (batch_max > lmax) {  // (wave-uniform) batches with longer reads only
         const unsigned int s1 = gf_wave_append(long1k, ctr + 2);
         if (long1k) list_long[s1] = (uint32_t)r;
@@ -769,6 +937,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       }
       r0 += nfit;
     }
+  }
+  if constexpr (QUEUED) {  // what is left of the wave's queue
+    while (q_len > 0) q_len = gf_filter_queue_pass<PW>(T, s_q, q_len, lane, counts, my_list, &s_cnt);
   }
   __syncthreads();
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt;

@@ -71,6 +71,11 @@ struct GfTable {
   // key.  Interleaved so that one cache line serves both.
   const uint32_t* gdu;
   uint32_t gd_words;        // word pairs in gdu: positions 0 .. 16 * gd_words - 1 are addressable
+  // The same pairs once more in overlapping 128-byte tiles (r04; nullptr = not built): tile t = pairs 6t .. 6t+15,
+  // so the 11 pairs a 150-base read's diagonal needs (seed+verify, reads of up to 160 bases) starting at ANY pair p
+  // lie in ONE cache line — tile p / 6, from its pair p % 6 on — where the plain array's 88 bytes straddle two lines
+  // for 10 of the 16 starting positions (1.7 missed lines per on-target read).  2.67 x the bytes.
+  const uint32_t* gdt;
   // presence filter over 14-mers (one 32-bit word, two bits per element), consulted
   // before any bucket probe of a window that is expected to miss.  For every key of the
   // table its last 14 bases (key >> 4) and its first 14 bases (key & 0x0FFFFFFF) are

@@ -260,6 +260,7 @@ struct gf_index {
   uint32_t* d_lin_hi = nullptr;
   uint32_t* d_gene_len = nullptr;
   uint32_t* d_gdu = nullptr;
+  uint32_t* d_gdt = nullptr;  // the same in overlapping 128-byte tiles (GfTable::gdt)
   uint32_t* d_bloom = nullptr;
   // first pass for reads <= 256 bases: 0 = flat pipeline (pack, seed+verify, probe, exact
   // kernel on survivors), 1 = wave-per-read probe-all, 2 = wave-per-read seed+verify
@@ -302,6 +303,7 @@ struct gf_index {
     block_free(device, d_lin_hi);
     block_free(device, d_gene_len);
     block_free(device, d_gdu);
+    block_free(device, d_gdt);
     block_free(device, d_bloom);
     block_free(device, d_cat);
     block_free(device, d_gene_off);
@@ -479,7 +481,13 @@ static int launch_flat(const gf_index* idx, const GfTable& T, hipStream_t st, co
   if (ev) GF_HIP(hipEventRecord(ev[0], st));
   // Seed+verify is bound by the line fills of its CU's L1, not by waves in flight: four blocks
   // per CU (40 KB of LDS each, padded with dynamic LDS) measured 2.5 % faster than six.
+  // (r04: the PW = 10 kernel's queue of background reads takes 24 KB of LDS itself — 36 KB per block, four blocks per CU
+  //  again without padding; GF_SV_INLINE_ROUNDS builds, the r03 form, pad as before)
+#ifdef GF_SV_INLINE_ROUNDS
   size_t pad_lds = PW == 10 ? 24000 : 0;
+#else
+  size_t pad_lds = 0;
+#endif
   if (const char* e = getenv("GF_SV_PAD_LDS")) pad_lds = (size_t)atoi(e);  // experiments
   hipLaunchKernelGGL((gf_k_seedverify_stream<PW, PACKED>), dim3(p.nblk), dim3(256), pad_lds, st, T, bases, src.pk, src.iv, offsets, n,
                      lmax, batch_max, counts, (GfPipeEntryW<PW>*)w.list_b, w.blk_cnt, p.per_block, w.list_long, w.ctr);
@@ -876,6 +884,16 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
     hipLaunchKernelGGL(gf_k_sort_dupes, dim3(sweep_grid), dim3(256), 0, 0, ix->d_slots, nslots, ix->d_dupes);
     GF_HIP(hipGetLastError());
   }
+  // the strands + flags once more in overlapping tiles, now that the flags are final (gf_table.h: gdt)
+  static const bool gdu_tiles = !(getenv("GF_GDU_TILES") && atoi(getenv("GF_GDU_TILES")) == 0);  // (0: experiments)
+  if (gdu_tiles) {
+    const uint32_t n_tiles = (uint32_t)((gd_words + GF_GDT_STRIDE - 1) / GF_GDT_STRIDE) + 1;
+    GF_HIP(block_alloc(dev, (void**)&ix->d_gdt, (size_t)n_tiles * 128));
+    hipLaunchKernelGGL(gf_k_gdu_tiles, dim3((n_tiles * 16u + 255u) / 256u), dim3(256), 0, 0, (const uint2*)ix->d_gdu,
+                       (uint32_t)gd_words, (uint2*)ix->d_gdt, n_tiles);
+    GF_HIP(hipGetLastError());
+    ix->table.gdt = ix->d_gdt;
+  }
   GF_HIP(hipDeviceSynchronize());
   lap("list sort");
 
@@ -903,7 +921,8 @@ int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32
   I.n_dupe_sites = (int64_t)stats[5];
   I.n_buckets = nbuckets;
   I.table_bytes = (int64_t)(nslots * sizeof(uint64_t) + dupes_cap * sizeof(uint32_t) +  // (as allocated)
-                            2 * gd_words * sizeof(uint32_t) + (size_t)bloom_words * sizeof(uint32_t));
+                            2 * gd_words * sizeof(uint32_t) + (size_t)bloom_words * sizeof(uint32_t) +
+                            (ix->d_gdt ? ((gd_words + GF_GDT_STRIDE - 1) / GF_GDT_STRIDE + 1) * 128 : 0));
   I.device = dev;
   *out_index = ix.release();
   return GF_OK;
