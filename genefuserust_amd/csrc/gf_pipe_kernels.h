@@ -958,12 +958,14 @@ __device__ __forceinline__ void gf_entries_to_lds(gf_u32x4* s_ent, const GfPipeE
 }
 template <int PW>
 __device__ __forceinline__ void gf_entry_from_lds(const gf_u32x4* s_ent, uint32_t& r, uint32_t& v1v2,
-                                                  uint32_t (&m)[GfPipeEntryW<PW>::NT], uint32_t (&pk)[PW + 1]) {
+                                                  uint32_t (&m)[GfPipeEntryW<PW>::NT], uint32_t (&pk)[PW + 1],
+                                                  unsigned int e = 0xFFFFFFFFu) {
   constexpr int NT = GfPipeEntryW<PW>::NT, EW = GfPipeEntryW<PW>::EW, EWP = EW + 1;
+  if (e == 0xFFFFFFFFu) e = threadIdx.x;  // (entry e of the chunk; by default the thread's own)
   uint32_t w[4 * EW];
 #pragma unroll
   for (int j = 0; j < EW; ++j) {
-    const gf_u32x4 q = s_ent[threadIdx.x * EWP + j];
+    const gf_u32x4 q = s_ent[e * EWP + j];
     w[4 * j] = q.x; w[4 * j + 1] = q.y; w[4 * j + 2] = q.z; w[4 * j + 3] = q.w;
   }
   r = w[0];
@@ -1007,8 +1009,15 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
   // The block's 256 entries of a round go in and out through LDS: a lane fetching its own 64-byte entry as four
   // 16-byte loads touches a line per load (64 lanes, 64 lines, four times over), the block fetching the chunk as one
   // contiguous run touches each line once — a third of this kernel's L2 requests were its entries (r03, §5).
+  // r04: the kernel is bound by instruction issue, and its lanes were busy 39 % of the time (SQ_THREAD_CYCLES_VALU):
+  // an entry WITH a candidate diagonal takes another path (forty look-ups of its own) than one without, they are a per
+  // cent or two of the list, and one of them among a wave's 64 entries makes the whole wave run both paths — 62 % of
+  // the waves did.  So a chunk's entries are dealt out by kind: the ones without a candidate to the block's first
+  // threads, the ones with to its last; at most one of the four waves holds both kinds.
   constexpr int EW = GfPipeEntryW<PW>::EW, EWP = EW + 1;  // (+1 vector of padding per entry: LDS banks)
   __shared__ gf_u32x4 s_ent[256 * EWP];
+  __shared__ unsigned short s_perm[256];  // thread -> entry of the chunk it works on (0xFFFF: none)
+  __shared__ unsigned int s_kind[2][4];   // entries without / with a candidate, per wave of the block
   __shared__ unsigned int s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
@@ -1021,15 +1030,43 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
     const unsigned int t = t0 + threadIdx.x;
     const unsigned int cnt = nb - t0 < 256u ? nb - t0 : 256u;
     gf_entries_to_lds<PW>(s_ent, my_list + t0, cnt);
+    s_perm[threadIdx.x] = 0xFFFFu;
     __syncthreads();
+    {  // deal the chunk's entries out by kind (see above)
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      bool with_cand = false;
+      if (t < nb) {
+        const gf_u32x4 q0 = s_ent[threadIdx.x * EWP];
+        const uint32_t h = q0.y;  // v1 | v2 << 8 | flags
+        with_cand = (h & GF_ENTRY_FILTERED) == 0 && T.bloom_words != 0 && !(PW == 10 && (h & 0xFFFFu) == 0);
+      }
+      const uint64_t mc = __ballot(with_cand), mn = __ballot(t < nb && !with_cand);
+      if (lane == 0) {
+        s_kind[0][wv] = (unsigned int)__popcll(mn);
+        s_kind[1][wv] = (unsigned int)__popcll(mc);
+      }
+      __syncthreads();
+      unsigned int before_n = 0, before_c = 0;
+      for (int k = 0; k < wv; ++k) {
+        before_n += s_kind[0][k];
+        before_c += s_kind[1][k];
+      }
+      if (t < nb) {
+        const unsigned int pos = with_cand ? 255u - (before_c + (unsigned int)gf_lanes_below(mc))
+                                           : before_n + (unsigned int)gf_lanes_below(mn);
+        s_perm[pos] = (unsigned short)threadIdx.x;
+      }
+      __syncthreads();
+    }
+    const unsigned int ent = s_perm[threadIdx.x];
     bool alive = false;
     constexpr int NT = GfPipeEntryW<PW>::NT;
     uint32_t r = 0, v1v2 = 0, m[NT], pk[PW + 1];
     uint32_t pp[NT];  // windows the filter could not rule out
 #pragma unroll
     for (int k = 0; k < NT; ++k) m[k] = pp[k] = 0;
-    if (t < nb) {
-      gf_entry_from_lds<PW>(s_ent, r, v1v2, m, pk);
+    if (ent != 0xFFFFu) {
+      gf_entry_from_lds<PW>(s_ent, r, v1v2, m, pk, ent);
       const bool filtered = (v1v2 & GF_ENTRY_FILTERED) != 0;  // every window listed has been through the filter
       const int v1 = (int)(v1v2 & 0xFFu), v2 = (int)((v1v2 >> 8) & 0xFFu);
       const bool no_candidate = PW == 10 && !filtered && v1 == 0 && v2 == 0 && T.bloom_words != 0;

@@ -9,10 +9,10 @@
 #  undecided: their times include 64 bytes of list entry per read.)
 set -e
 REPO=$(cd $(dirname $0)/.. && pwd)
-VARIANTS="sv6:-DGF_ABLATE_SV=6 sv5:-DGF_ABLATE_SV=5 noinl:-DGF_SV_NO_INLINE_FILTER w6:-DGF_SVS_WAVES_PER_SIMD=6 w8:-DGF_SVS_WAVES_PER_SIMD=8"
+VARIANTS="sv6:-DGF_ABLATE_SV=6 sv5:-DGF_ABLATE_SV=5 sv3:-DGF_ABLATE_SV=3 sv4:-DGF_ABLATE_SV=4 noinl:-DGF_SV_NO_INLINE_FILTER"
 if [ "$1" = build ]; then
   for v in $VARIANTS; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 ${v#*:} -shared \
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 ${v#*:} -Wno-unused-function -shared -L/opt/rocm/lib -lrccl \
       -o $REPO/genefuserust_amd/libgfmatch_${v%%:*}.so $REPO/genefuserust_amd/csrc/gfmatch.hip &
   done
   wait
@@ -20,7 +20,7 @@ else
   for v in full $VARIANTS; do
     name=${v%%:*}
     lib=$REPO/genefuserust_amd/libgfmatch_$name.so; [ $name = full ] && lib=$REPO/genefuserust_amd/libgfmatch.so
-    GFMATCH_LIB=$lib python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity "${@:2}" 2>/dev/null | \
+    GFMATCH_LIB=$lib python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity --no-h2d --no-pack-sweep --no-stress "${@:2}" 2>/dev/null | \
       python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', d['roofline']['kernel_ms_avg'], d['roofline']['stage_ms'])"
   done
 fi

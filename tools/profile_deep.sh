@@ -13,7 +13,7 @@ KEEP=$REPO/gpurun_out/prof_$TAG   # summaries and logs (gpurun copies back at mo
 OUT=/tmp/prof_$TAG                # raw counter CSVs stay on the box
 mkdir -p $OUT $KEEP
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-h2d $*"
+BENCH="python3 $REPO/bench.py --steps 3 --warmup 1 --profile-mode $*"
 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1 || true
 i=0
 for pmc in \
