@@ -475,6 +475,16 @@ __global__ void gf_k_index_side(const GfSideEntry* __restrict__ side, unsigned l
     uint64_t* s = gf_find_slot(slots, nbuckets, e.key);
     if (!s) continue;
     const uint32_t val = *(const uint32_t*)s;
+    if (((val & GF_VAL_LOW) >> GF_TYPE_SHIFT) == GF_TYPE_HIGH) {
+      // r04: a key with six sites or more cannot vote (indexer.rs:202-239), and a read that lies in a repeat shows
+      // nothing else — the bucket pass probed fifty of its windows one after the other to learn it.  Every site of
+      // such a key gets a flag (the odd bit beside its "unique" flag) and the key's slot the smallest of its sites:
+      // one probe that comes back HIGH then leads to a copy of the repeat in the genes, and every window of the
+      // read that equals a flagged site there is PROVEN unable to vote (gf_k_probe_buckets).
+      atomicOr(gdu + 2 * (size_t)(e.lin >> 4) + 1, 2u << (2u * (e.lin & 15u)));
+      atomicMin((unsigned int*)s, (val & ~GF_LIN_MASK) | (e.lin & GF_LIN_MASK));  // (the bits above the site field are final here)
+      continue;
+    }
     if (((val & GF_VAL_LOW) >> GF_TYPE_SHIFT) != GF_TYPE_DUPES) continue;
     const uint32_t cnt = (val >> GF_DUPE_COUNT_SHIFT) & 7u, start = val & GF_DUPE_START_MASK;
     for (uint32_t k = 0; k < cnt; ++k) {
@@ -809,7 +819,8 @@ __global__ __launch_bounds__(256) void gf_k_classify_assign(uint64_t* slots, uin
         nv = (GF_TYPE_DUPES << GF_TYPE_SHIFT) | (c << GF_DUPE_COUNT_SHIFT) | (start & GF_DUPE_START_MASK);
         start += c;
       } else {
-        nv = GF_TYPE_HIGH << GF_TYPE_SHIFT;
+        // (the site field: a representative site of the key, the smallest — gf_k_index_side; all ones = none yet)
+        nv = (GF_TYPE_HIGH << GF_TYPE_SHIFT) | GF_LIN_MASK;
       }
       *(uint32_t*)(slots + 2 * (p0 + 256u * (k >> 1)) + (k & 1)) = (val[k] & GF_VAL_OVF) | nv;
     }

@@ -1218,7 +1218,9 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
 // pass B of seed+verify on an entry's words (registers, the read starts at bit 0 of pk[0]): the windows whose 16 bases
 // equal the bases of site K + 2w and whose site is the only one of its key, one bit per stride-2 window.  No
 // "bad base" stream here: the caller intersects the result with windows known to be clean.
-template <int PW>
+// HIGHBIT: the windows whose 16 bases equal the bases of site K + 2w and whose site belongs to a key of six sites or
+// more (the odd flag bits, gf_k_index_side) instead: windows PROVEN unable to vote.
+template <int PW, bool HIGHBIT = false>
 __device__ __forceinline__ void gf_verify_words(const GfTable& T, const uint32_t (&pk)[PW + 1], uint32_t K,
                                                 uint32_t (&vmb)[GfPipeEntryW<PW>::NT]) {
   constexpr int NT = GfPipeEntryW<PW>::NT;
@@ -1241,7 +1243,8 @@ __device__ __forceinline__ void gf_verify_words(const GfTable& T, const uint32_t
       const uint32_t x = pk[j + 1] ^ __builtin_amdgcn_alignbit(gw[j + 2 <= PW ? j + 2 : PW].x, gw[j + 1].x, bo);
       zz_next = (x | (x >> 1)) & 0x55555555u;
     }
-    const uint32_t u = __builtin_amdgcn_alignbit(gw[j + 1].y, gw[j].y, bo);
+    uint32_t u = __builtin_amdgcn_alignbit(gw[j + 1].y, gw[j].y, bo);
+    if (HIGHBIT) u >>= 1;
     const uint32_t ver = gf_clean16(zz_cur, zz_next) & u & 0x11111111u;
     vmb[j >> 2] |= gf_gather_nibble_lsb(ver) << (8 * (j & 3));
     zz_cur = zz_next;
@@ -1324,6 +1327,7 @@ __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPip
         for (int u = 0; u < 4; ++u)
           if (act[u]) val[u] = gf_lookup<GF_PROBE_NT>(T, key[u]);
         uint32_t K = GF_NONE_LIN;
+        uint32_t Kh = GF_NONE_LIN;  // a copy of the repeat this read lies in: the diagonal of a HIGH key's representative site
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (act[u]) {
@@ -1332,8 +1336,22 @@ __global__ __launch_bounds__(256) void gf_k_probe_buckets(GfTable T, const GfPip
               h += 1;
               voted[wv[u] >> 5] |= 1u << (wv[u] & 31);
               if (want_k && ty == GF_TYPE_UNIQUE && K == GF_NONE_LIN) K = (val[u] & GF_LIN_MASK) - 2u * (uint32_t)wv[u];
+            } else if (ty == GF_TYPE_HIGH && (val[u] & GF_LIN_MASK) != GF_LIN_MASK && Kh == GF_NONE_LIN) {
+              Kh = (val[u] & GF_LIN_MASK) - 2u * (uint32_t)wv[u];
             }
             left -= 1;
+          }
+        }
+        if (PW == 10 && Kh != GF_NONE_LIN) {
+          // r04: windows whose bases equal a site of a key with six sites or more are proven unable to vote — all of
+          // them at once, where each used to cost a probe of its own (a read inside a repeat: fifty probes in a row)
+          uint32_t hk[NT];
+          gf_verify_words<PW, true>(T, pk, Kh, hk);
+          left = 0;
+#pragma unroll
+          for (int k = 0; k < NT; ++k) {
+            p[k] &= ~hk[k];  // (windows past the read's end compared garbage: none of them stands in p)
+            left += __popc(p[k]);
           }
         }
         if (K != GF_NONE_LIN) {

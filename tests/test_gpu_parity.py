@@ -273,6 +273,37 @@ def test_synthetic_parity_medium(gpu_device, oracle, shape, scale, n_reads, vari
     ix.close()
 
 
+@pytest.mark.parametrize("shape,scale", [("IDX-T", 0.3), ("IDX-C", 0.03)])
+def test_repeat_rich_genes_parity(gpu_device, oracle, shape, scale):
+    """Genes of which 30 % are copies of a 20-element repeat family and 5 % poly-A / tandem repeats: reads inside a
+    repeat show nothing but keys with six sites or more (HIGH: they cannot vote, indexer.rs:202-239), reads across a
+    repeat's edge mix them with unique keys.  The bucket pass proves whole stretches of such windows unable to vote from
+    ONE probe (the key's representative site + the per-site HIGH flags, r04): every read's result equals the oracle's."""
+    from genefuserust_amd import Indexer, synth
+    genes = synth.make_geneset(shape, scale=scale, repeat_frac=0.3, low_complexity_frac=0.05)
+    ix = Indexer.from_gene_slices(genes.seqs, genes.reversed_flags)
+    ix.make_index()
+    ox = oracle.OracleIndexer(genes.seqs)
+    info, st = ix.info(), ox.stats()
+    assert (info["n_keys"], info["n_high_keys"], info["n_unique"]) == (st["n_keys"], st["n_high_keys"], st["m_unique_pos"])
+    assert info["n_high_keys"] > 200
+    synth.MIXES["TEST"] = (0.1, 0.6, 0.3)
+    total_hits = 0
+    for L in (150, 100, 251):
+        rb = synth.make_reads(genes, 40000, read_len=L, mix="TEST", seed=31 + L)
+        bases, offsets = rb.bases.numpy(), rb.offsets.numpy()
+        counts, matches = ix.map_reads_packed(bases, offsets)
+        ocounts, omatches = ox.map_reads_packed(bases, offsets, threads=8)
+        assert (counts == ocounts).all(), np.nonzero(counts != ocounts)[0][:10]
+        nz = counts > 0
+        assert (matches[nz, 0] == omatches[nz, 0]).all()
+        two = counts == 2
+        assert (matches[two, 1] == omatches[two, 1]).all()
+        total_hits += int(nz.sum())
+    assert total_hits > 500
+    ix.close()
+
+
 def test_cpp_host_mirror(gpu_device, tmp_path):
     """include/gf_indexer.hpp (the compiled-language host side above the C ABI):
     planted-fusion known answer through the C++ Indexer mirror."""

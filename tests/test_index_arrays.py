@@ -1,5 +1,5 @@
 """The index's derived device arrays, word by word: the genes of both strands in site-code space, the
-"only site of its key" flags and the presence filter over canonical 14-mers (csrc/gf_index_kernels.h,
+"only site of its key" / "one of six or more" flags and the presence filter over canonical 14-mers (csrc/gf_index_kernels.h,
 layout in csrc/gf_table.h) are what the mapping kernels verify candidates against — a wrong word there is
 hidden from the mapping tests wherever the exact kernel repairs the result.  Here they are rebuilt on the
 host from the gene slices alone, following Indexer::make_index / index_contig (src/core/indexer.rs:122-250:
@@ -100,6 +100,9 @@ def _expected(genes, lin_base, gd_words, filter_words):
         if len(where) == 1:
             p = where[0]
             flags[p >> 4] |= 1 << (2 * (p & 15))
+        if len(where) >= 6:                # r04: every site of a key that cannot vote (>= 6 sites) carries the odd bit
+            for p in where:
+                flags[p >> 4] |= 2 << (2 * (p & 15))
         for s14 in (key & 0x0FFFFFFF, key >> 4):
             w, b = _filter_bits(s14, filter_words)
             filt[w] |= b
@@ -126,7 +129,8 @@ def test_strands_flags_and_filter_word_by_word(gpu_device):
         bad = np.nonzero(got_flags != flags)[0]
         assert bad.size == 0, ("unique flags differ", bad[:5], [hex(int(got_flags[i])) for i in bad[:5]],
                                [hex(int(flags[i])) for i in bad[:5]])
-        assert int(flags.astype(np.uint64).sum()) > 0 and int((flags & 0xAAAAAAAA).sum()) == 0
+        assert int((flags & 0x55555555).astype(np.uint64).sum()) > 0 and int((flags & 0xAAAAAAAA).astype(np.uint64).sum()) > 0
+        assert int((flags & (flags >> 1) & 0x55555555).sum()) == 0    # no site is both the only one of its key and one of six
         # the filter holds exactly the canonical 14-mers of the keys: no missing bit (a false negative would
         # drop reads), no bit more than the build rule gives
         bad = np.nonzero(filt != want_filter)[0]
@@ -234,7 +238,9 @@ def test_a_gene_list_with_every_gene_repeated(gpu_device, copies):
         gdu, filt, lin_base = _export(ix, 0), _export(ix, 1), _export(ix, 2)
         even, flags, want_filter, sites = _expected(genes, lin_base, gdu.shape[0] // 2, filt.shape[0])
         assert (gdu[0::2] == even).all() and (gdu[1::2] == flags).all() and (filt == want_filter).all()
-        assert int(flags.astype(np.uint64).sum()) == 0   # nobody is the only site of its key
+        assert int((flags & 0x55555555).astype(np.uint64).sum()) == 0   # nobody is the only site of its key
+        # ... and with six copies every site is one of six or more: the odd bits (r04) mark them all
+        assert (int((flags & 0xAAAAAAAA).astype(np.uint64).sum()) > 0) == (copies >= 6)
         info = ix.info()
         n_sites = sum(len(v) for v in sites.values())
         assert info["n_keys"] == len(sites) and info["n_sites"] == n_sites and info["n_unique"] == 0
