@@ -652,6 +652,15 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             filt_done = true;
             if (nvalid < GF_MAJOR_KEYS / 2) {
               filt_dead = true;
+            } else if (khigh[0] | khigh[1]) {
+              // a seed is in the table with six sites or more: most likely a read inside a repeat, every window of
+              // which the filter will call present — it skips the rounds and goes on as it is; the bucket pass strikes
+              // its windows from one probe (gf_k_probe_buckets, r04).  Listing windows the filter was not asked about
+              // as "filtered" is sound: the mark only says nobody need ask again.
+#pragma unroll
+              for (int k = 0; k < NT; ++k) pp[k] = cwb[k];
+              pp[0] |= khigh[0];
+              pp[1] |= khigh[1];
             } else {
               queued = true;
 #pragma unroll
