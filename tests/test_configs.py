@@ -118,7 +118,7 @@ def test_sharded_real_hit_lists_merge_to_the_one_shot_list_gloo(oracle):
 
 # ---------------------------------------------------------------- GPU
 
-def _full_size_properties(oracle, shape, n, L=150, seed=4242, min_hits=5_000, max_hits=200_000):
+def _full_size_properties(oracle, shape, n, L=150, seed=4242, min_hits=5_000, max_hits=200_000, pairs=False):
     import torch
     from genefuserust_amd import Indexer, synth
     from genefuserust_amd.indexer import hits_to_numpy
@@ -128,7 +128,10 @@ def _full_size_properties(oracle, shape, n, L=150, seed=4242, min_hits=5_000, ma
     ox = oracle.OracleIndexer(genes.seqs)
     st, info = ox.stats(), ix.info()
     assert (info["n_keys"], info["n_high_keys"], info["n_unique"]) == (st["n_keys"], st["n_high_keys"], st["m_unique_pos"])
-    rb = synth.make_reads(genes, n, read_len=L, mix="PANEL", seed=seed, device="cuda")
+    if pairs:   # the bench's own workload: SURVEY.md 8(d) pairs, R1, R2, R1, R2 ..
+        rb = synth.make_pair_reads(genes, n // 2, read_len=L, mix="PANEL", seed=seed, device="cuda")
+    else:
+        rb = synth.make_reads(genes, n, read_len=L, mix="PANEL", seed=seed, device="cuda")
     counts, matches = ix.map_reads_device(rb.bases, rb.offsets, L)
     torch.cuda.synchronize()
     assert int((counts > 2).sum()) == 0
@@ -179,6 +182,17 @@ def test_config2_full_size_cancer_shaped_index(gpu_device, oracle):
     independence, ordered compaction."""
     info = _full_size_properties(oracle, "IDX-C", 20_000_000, seed=20240117)
     assert info["n_keys"] > 25_000_000 and info["table_bytes"] > 400_000_000
+
+
+@pytest.mark.gpu
+def test_config2_full_batch(gpu_device, oracle):
+    """BASELINE configs[2] at its real BATCH as well: 100 M PANEL pairs = 200 M reads = 30 GB of bases in
+    one call — byte offsets past 2^31 and 2^34, the 8192-block plan, a 13 GB workspace — against the cancer-shaped
+    index.  Every read with segments and 100 K others re-mapped by the oracle; determinism; order independence;
+    ordered compaction.  (The box has 288 GB of HBM; this takes about 90 of them.)"""
+    info = _full_size_properties(oracle, "IDX-C", 200_000_000, seed=20240117 + 1000, min_hits=20_000, max_hits=4_000_000,
+                                 pairs=True)
+    assert info["n_keys"] > 25_000_000
 
 
 @pytest.mark.gpu
