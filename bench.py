@@ -944,10 +944,17 @@ def bench_multi_csv(args, cfg, world, rank, local_rank, dev, barrier, seed, gene
             "achieved": measured if measured is not None else algo_gbps,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (measured if measured is not None else algo_gbps) / HBM_PEAK_GBS if (measured or algo_gbps) else None,
-            "frac_definition": ("measured: (32 B x TCC_EA0_RDREQ_DRAM_32B + WRITE_SIZE) of every kernel of a step / the step's wall time / 8 TB/s"
+            "frac_definition": ("measured: L2 <-> fabric bytes (incl. Infinity-Cache hits) = (32 B x TCC_EA0_RDREQ_DRAM_32B + WRITE_SIZE) of every "
+                                "kernel of a step / the step's wall time / 8 TB/s"
                                 if measured is not None else
                                 "ALGORITHMIC (no counter measurement for this workload): 706 B per read and CSV / host-timed mapping time / 8 TB/s"),
             "traffic": traffic, "traffic_source": (te or {}).get("source"),
+            "traffic_build": None if not te else {"git_head": te.get("git_head"), "kernel_src_sha": te.get("kernel_src_sha"),
+                                                  "lib_sha": te.get("lib_sha")},
+            "traffic_stale": (te.get("kernel_src_sha") != kernel_source_sha()) if te else None,
+            "loaded_build": {"kernel_src_sha": kernel_source_sha(), "lib_sha": library_sha()},
+            "hbm_only": None,
+            "hbm_only_note": "not separable: rocprofv3 on gfx950 exposes no Infinity-Cache (MALL) or memory-controller counter",
             "algorithmic_GBps": algo_gbps, "algorithmic_frac": algo_gbps / HBM_PEAK_GBS if algo_gbps else None,
             "share_of_step_in_index_rebuild": tot_build / (tot_build + tot_map) if tot_build + tot_map else None,
         }
