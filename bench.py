@@ -22,7 +22,7 @@ all-gather of the per-rank hit lists (the path's only exchange).  --config picks
 One process per GPU.  `python bench.py --gpus N` without WORLD_SIZE in the environment starts its N ranks
 itself (a child `python -m torch.distributed.run ... bench.py <same arguments>`, before this process touches the
 GPU) and relays rank 0's line and the child's exit code; under torch.distributed.run it is a rank.  Rank 0 prints
-ONE JSON line (see DESIGN.md "Measurement").
+ONE JSON line ("Measurement").
 """
 import argparse
 import json
@@ -577,11 +577,13 @@ def roofline_object(args, cfg, n, L, kern_ms_avg, stage_ms):
     measured = traffic / secs / 1e9 if traffic else None
     achieved = measured if measured is not None else algo_gbps
     return {
-        "bound": "l2_tag",
-        "binding_resource": "the XCDs' L2s, hits and misses adding up: seed+verify's time follows 4.8 ps per L2 hit (the presence "
-                            "filter's look-ups) + 14.8 ps per L2 miss (a 128-byte line over the fabric each: bases, buckets, genes, "
-                            "evicted filter lines) across filter sizes and read mixes; with every other CU masked off it takes the "
-                            "same time, with half the XCDs twice as long (DESIGN.md 5)",
+        "bound": "hbm",
+        "binding_resource": "vector instruction issue (measured, r04): nine more vector instructions per filter look-up, no memory "
+                            "access, cost seed+verify +14 % of its time; 786 M vector + 157 M scalar instructions per 20 M reads, the "
+                            "vector ALUs issuing 73 % of the cycles at four waves per SIMD.  No MFMA: integer hashing.  The fraction "
+                            "below is of the HBM peak because that is the roofline a byte-moving path is held against; r03's "
+                            "'4.8 ps per L2 hit + 14.8 ps per miss' fitted because hits and instructions both scale with the look-ups "
+                            "(DESIGN.md 5)",
         "kernel": {0: "gf_map_reads_device = 4 kernels: gf_k_seedverify_stream (dominant) + gf_k_probe_filter + "
                       "gf_k_probe_buckets + gf_k_map_reads_list; their summed duration",
                    1: "gf_k_map_reads_short<4,0> (wave per read, probe-all)",
@@ -940,7 +942,7 @@ def bench_multi_csv(args, cfg, world, rank, local_rank, dev, barrier, seed, gene
         traffic = te["hbm_bytes_per_launch"] if te and world == 1 and not args.no_packed else None
         measured = traffic / step_s / 1e9 if traffic else None
         result["roofline"] = {
-            "bound": "l2_tag", "kernel": "one step = per CSV: index rebuild (K1) + mapping pass (4 kernels) + compaction; the reads packed once",
+            "bound": "hbm", "kernel": "one step = per CSV: index rebuild (K1) + mapping pass (4 kernels) + compaction; the reads packed once",
             "achieved": measured if measured is not None else algo_gbps,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (measured if measured is not None else algo_gbps) / HBM_PEAK_GBS if (measured or algo_gbps) else None,

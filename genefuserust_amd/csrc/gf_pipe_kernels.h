@@ -247,7 +247,9 @@ __device__ __forceinline__ uint32_t gf_window_mask(int nwin, int k) {
 // (the layout of a list entry, 64 bytes), and whenever 64 records wait, the wave runs ONE round for 64 of them, every
 // lane busy, each on its own record's round.  A record that outlives round 0 goes back into the queue for round 1;
 // one that outlives round 1 goes to the list as before; the others are decided ([]).  Same decisions, read by read.
+#ifndef GF_FQ_CAP
 #define GF_FQ_CAP 96  // records per wave: a tile adds at most 64 to at most 63 waiting (more: passes run first)
+#endif
 
 template <int PW>
 __device__ __forceinline__ int gf_filter_queue_pass(const GfTable& T, gf_u32x4* s_q, int q_len, int lane,
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // 12 for a 150-base read where 20 are needed, and a false positive of the filter adds 3.  A read the
           // bound does not stop (three false positives or more, or windows that really are in the table) asks
           // the odd pairs in round 1 and meets the bound again with everything known.  13 + 4 look-ups instead of
-          // 28 + 4 for a background read, and these look-ups are the kernel's bound.
+          // 28 + 4 for a background read, and these look-ups — their instructions, r04 found — are the kernel's bound.
           if (QUEUED && K == GF_NONE_LIN && T.bloom_in_l2 == 2) {
             // by queue (gf_filter_queue_pass): the standing windows go along; a read with fewer than 20 clean
             // windows left cannot reach the gate whatever the filter says
@@ -1013,7 +1015,7 @@ __global__ __launch_bounds__(256) void gf_k_probe_filter(GfTable T, GfPipeEntryW
   // itself) go by the bound of gf_table.h (r03): part by part every pair of windows is asked, and after the last part
   // the bound decides — far stronger than "fewer than 20 windows left": the bucket pass behind sees half the reads.
   // (Asking only the even pairs first, as seed+verify does, needs a third launch over the survivors for a filter
-  // in two parts, and a launch over the list costs 0.7 ms whatever it asks: 1.85 ms against 1.58)
+  // in two parts, and a launch over the list costs 0.7 ms whatever it asks: 1.85 ms against 1.58, NOTEBOOK.md §5.)
   // With the whole filter in one part the even pairs go first and the bound may stop the read before the odd ones.
   // The block's 256 entries of a round go in and out through LDS: a lane fetching its own 64-byte entry as four
   // 16-byte loads touches a line per load (64 lanes, 64 lines, four times over), the block fetching the chunk as one

@@ -1489,7 +1489,7 @@ static int stage_and_map(gf_index* mix, HostLane& L, const char* bases, const in
 // the reads are written to the lane's pinned block, the exact wave-per-read kernels fetch them over the link and
 // write their results back to the same block: ONE launch and one wait per call where the batch route is two
 // copies in, a memset, seven launches and two copies out — 12 queue operations whose cost, not the kernels', is
-// what a 2000-read call pays for (tools/bench_pack_sweep.py).
+// what a 2000-read call pays for (tools/bench_pack_sweep.py; DESIGN.md 4, "host calls").
 //   n <= GF_SMALL_CALL_READS (64):     one wave per read, probe-all kernel, a block per read
 //   n <= GF_PACK_CALL_READS:           the software-pipelined seed+verify kernel, grid-stride over the pack
 static int64_t small_call_reads() {

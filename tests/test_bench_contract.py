@@ -27,7 +27,7 @@ def test_line_has_the_contract_fields(c):
     r = j["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "l2_tag" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.2 < r["frac"] < 0.9
     assert j["parity"] and all(v["bit_exact"] for v in (j["parity"].values() if c == 4 else [j["parity"]]))
 

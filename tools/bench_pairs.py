@@ -111,7 +111,7 @@ def main():
     total = ms_cut1 + ms_cut2 + ms_scan
     text_bytes = int(t1.numel() + t2.numel())
     # roofline per stage: counter-measured bytes (tools/profile_pairs.sh -> profiles/frontend_traffic.json, calibrated as
-    # in DESIGN.md 5: read = 32 B x TCC_EA0_RDREQ_DRAM_32B, written = WRITE_SIZE) over this run's stage time, and the
+    # in NOTEBOOK.md §5 r03: read = 32 B x TCC_EA0_RDREQ_DRAM_32B, written = WRITE_SIZE) over this run's stage time, and the
     # stage's algorithmic in + out bytes (text in; bases, qualities, offsets out / records in, hit records out)
     roof = {}
     try:

@@ -1,4 +1,4 @@
-// Micro-benchmarks behind DESIGN.md §4 K1's pricing of a partitioned index build (r03): what the pieces a build is
+// Micro-benchmarks behind NOTEBOOK.md §4 K1's pricing of a partitioned index build (r03): what the pieces a build is
 // made of cost on this chip, each over N = 30 M items (a cancer-sized gene set's sites).
 //   0  atomicCAS on a random 8-byte slot of a 467 MB table        (today's gf_k_index_insert, minus everything else)
 //   1  atomicOr on a random word of a 15 MB array                  (unique flags, one atomic per site)

@@ -1,5 +1,5 @@
 // Micro-benchmark: can the scalar data path carry scattered 4-byte look-ups of an L2-resident table beside the
-// vector path?  gf_k_seedverify_stream is bound by the L1's miss queue (~86 requests in flight per
+// vector path?  gf_k_seedverify_stream is bound by the L1's miss queue (NOTEBOOK.md §5, r01-r03's reading: ~86 requests in flight per
 // CU x 351 cycles), at 56 % of the L2's look-up rate; scalar loads have a queue of their own.
 //   ./mb_scalar_gather [table_KiB=3072] [iters=2000]
 // mode V: 4 vector look-ups per lane and iteration; mode S: SPER scalar look-ups per wave and iteration;
