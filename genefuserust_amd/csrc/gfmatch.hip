@@ -1584,6 +1584,9 @@ static int zc_wait(ZeroCopy& Z, hipStream_t st) {
     for (uint64_t spin = 1;; ++spin) {
       if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == Z.seq) { done = true; break; }
       __builtin_ia32_pause();
+      // a kernel that takes longer than a pack's few tens of microseconds (the device is busy with somebody's batch):
+      // the core goes to whoever else wants it between looks
+      if (spin > 4096) std::this_thread::yield();
       if ((spin & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
     }
     if (done && ++Z.unsynced >= 64) done = false;
