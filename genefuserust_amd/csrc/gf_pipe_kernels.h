@@ -340,6 +340,106 @@ __device__ __forceinline__ int gf_filter_queue_pass(const GfTable& T, gf_u32x4* 
   return base + __popcll(am);
 }
 
+// ---- reads with a HIGH seed, by the same queue's other end (r04) ----
+// A read whose seeds name no diagonal but one of which is in the table with six sites or more lies, most likely, inside a
+// repeat: every window the filter is asked about is present, every bucket probed comes back HIGH.  Such a key keeps a
+// representative site (gf_k_index_side) and every site of such a key a flag: the read is verified against the genes on
+// the representative's diagonal like an on-target read on its candidate's — windows that equal a site which is the only
+// one of its key are votes for that diagonal (v1), windows that equal a flagged site are PROVEN unable to vote (their
+// key is that site's key) — and with `open` = the clean windows that are neither, the usual test decides it:
+// v1 + open < 20 or open < 10 -> [].  These reads are a fraction of a per cent on SURVEY.md 8(d)'s genes and a fifth
+// of all reads on genes with 30 % repeats, so they wait at the BACK of the wave's queue (records: read, diagonal, clean
+// windows, packed words) and are verified 64 at a time.
+template <int PW>
+__device__ __forceinline__ void gf_verify_words2(const GfTable& T, const uint32_t* pk, uint32_t K,
+                                                 uint32_t (&vmb)[GfPipeEntryW<PW>::NT], uint32_t (&hmb)[GfPipeEntryW<PW>::NT]) {
+  constexpr int NT = GfPipeEntryW<PW>::NT;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) vmb[k] = hmb[k] = 0;
+  const uint2* gp = (const uint2*)T.gdu + (K >> 4);
+  if (PW == 10 && T.gdt != nullptr) {
+    const uint32_t p = K >> 4, t = __umulhi(p, 0xAAAAAAABu) >> 2;  // t = p / 6
+    gp = (const uint2*)T.gdt + 16u * t + (p - 6u * t);
+  }
+  const uint32_t bo = 2u * (K & 15u);
+  uint2 gw[PW + 1];
+#pragma unroll
+  for (int j = 0; j < PW + 1; ++j) gw[j] = gp[j];
+  uint32_t zz_cur;
+  {
+    const uint32_t x = pk[0] ^ __builtin_amdgcn_alignbit(gw[1].x, gw[0].x, bo);
+    zz_cur = (x | (x >> 1)) & 0x55555555u;
+  }
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    uint32_t zz_next = 0x55555555u;
+    if (j + 1 < PW) {
+      const uint32_t x = pk[j + 1] ^ __builtin_amdgcn_alignbit(gw[j + 2 <= PW ? j + 2 : PW].x, gw[j + 1].x, bo);
+      zz_next = (x | (x >> 1)) & 0x55555555u;
+    }
+    const uint32_t u = __builtin_amdgcn_alignbit(gw[j + 1].y, gw[j].y, bo);
+    const uint32_t clean = gf_clean16(zz_cur, zz_next);
+    vmb[j >> 2] |= gf_gather_nibble_lsb(clean & u & 0x11111111u) << (8 * (j & 3));
+    hmb[j >> 2] |= gf_gather_nibble_lsb(clean & (u >> 1) & 0x11111111u) << (8 * (j & 3));
+    zz_cur = zz_next;
+  }
+}
+
+template <int PW>
+__device__ __forceinline__ int gf_high_queue_pass(const GfTable& T, gf_u32x4* s_q, int q_back, int lane,
+                                                  uint8_t* __restrict__ counts, GfPipeEntryW<PW>* my_list,
+                                                  unsigned int* s_cnt) {
+  static_assert(PW == 10, "the queue holds the 64-byte entries of reads of up to 160 bases");
+  constexpr int NT = GfPipeEntryW<PW>::NT;
+  const int m = q_back < 64 ? q_back : 64;
+  const int base = GF_FQ_CAP - q_back;  // the records added last (the back end grows downwards)
+  const bool act = lane < m;
+  uint32_t w[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) w[j] = 0;
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const gf_u32x4 q = s_q[(base + lane) * 4 + j];
+      w[4 * j] = q.x; w[4 * j + 1] = q.y; w[4 * j + 2] = q.z; w[4 * j + 3] = q.w;
+    }
+  }
+  bool emit = false;
+  if (act) {
+    uint32_t vk[NT], hk[NT];
+    gf_verify_words2<PW>(T, &w[2 + NT], w[1], vk, hk);  // (w[2 + NT + PW] does not exist: the function reads PW words)
+    int v1 = 0, h = 0, nvalid = 0;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const uint32_t cw = w[2 + k];  // clean windows (the words past the read's end compared garbage: masked here)
+      vk[k] &= cw;
+      hk[k] &= cw & ~vk[k];
+      v1 += __popc(vk[k]);
+      h += __popc(hk[k]);
+      nvalid += __popc(cw);
+      w[2 + k] = cw & ~vk[k] & ~hk[k];  // what may still vote for another diagonal
+    }
+    const int open = nvalid - v1 - h;
+    if (v1 + open < GF_MAJOR_KEYS / 2 || open < GF_MINOR_KEYS / 2) counts[w[0]] = 0;
+    else emit = true;
+    // v1 > 0: an entry with a candidate diagonal (counted windows are votes); v1 == 0: nobody need ask the filter about
+    // windows of a read that lies in the table all over — marked filtered, the bucket pass takes it from here
+    w[1] = v1 > 0 ? (uint32_t)v1 : GF_ENTRY_FILTERED;
+  }
+  const unsigned int slot_b = gf_wave_append_lds(emit, s_cnt);
+  if (emit) {
+    gf_u32x4* dst = (gf_u32x4*)(my_list + slot_b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gf_u32x4 q;
+      q.x = w[4 * j]; q.y = w[4 * j + 1]; q.z = w[4 * j + 2]; q.w = w[4 * j + 3];
+      dst[j] = q;
+    }
+  }
+  gf_wave_lds_sync();
+  return q_back - m;
+}
+
 // PACKED: the reads arrive as the 2-bit + bad-bit form of the whole `bases` stream (gf_pack_bases_device:
 // word c of g_pk / g_iv = bases 16c .. 16c+15, `offsets` still count bases) — a tile is then copied,
 // 6 bytes per 16 bases instead of 16, and nothing is converted.
@@ -376,7 +476,8 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
   uint32_t* s_pk = s_pk_all[wave];
   uint32_t* s_iv = s_iv_all[wave];
   gf_u32x4* s_q = s_q_all[QUEUED ? wave : 0];
-  int q_len = 0;  // records waiting in this wave's queue (wave-uniform)
+  int q_len = 0;   // records waiting at the front of this wave's queue: filter rounds (wave-uniform)
+  int q_back = 0;  // ... and at its back: reads with a HIGH seed
   const int64_t r_lo = (int64_t)blockIdx.x * per_block;
   int64_t n_lim = n;
   if (T.n_dev) {  // (the reads beyond the device-side count are empty slots nobody asks about)
@@ -463,7 +564,9 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       const bool in_range = lane < nfit;
       bool undecided = false, long1k = false, long4k = false;
       bool queued = false;  // a read without a candidate diagonal, on its way to the wave's filter queue
-      uint32_t pp_q[NT];    // ... and its standing windows
+      bool hqueued = false; // ... or, with a HIGH seed, to the queue's other end
+      uint32_t K_q = 0;     // (the diagonal it is verified on there)
+      uint32_t pp_q[NT];    // ... and its standing / clean windows
 #pragma unroll
       for (int k = 0; k < NT; ++k) pp_q[k] = 0;
       uint32_t e_v1v2 = 0, e_todo[NT];
@@ -556,6 +659,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           // striking it would split their run (r03: found by enumeration, tests/test_vote_bound.py)
           uint32_t khigh[2] = {0, 0};
           uint32_t K = GF_NONE_LIN;   // candidate diagonal: site code of read base 0
+          uint32_t Krep = GF_NONE_LIN;  // ... of a copy of the repeat the read may lie in (a HIGH seed's representative site)
           // Seed 0 first — filter, then its bucket: most reads that have a candidate diagonal get it
           // here, for one filter line into the L1 instead of four (the kernel is bound by those line
           // fills); the other three seeds are asked about only by the reads still without one.
@@ -574,7 +678,10 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             if (ty == GF_TYPE_UNIQUE) K = val & GF_LIN_MASK;
             else if (ty != GF_TYPE_DUPES) {
               kill[0] |= 1u;
-              if (ty == GF_TYPE_HIGH) khigh[0] |= 1u;
+              if (ty == GF_TYPE_HIGH) {
+                khigh[0] |= 1u;
+                if ((val & GF_LIN_MASK) != GF_LIN_MASK) Krep = val & GF_LIN_MASK;  // the key's representative site
+              }
             }
           }
           if (K == GF_NONE_LIN && (T.bloom_in_l2 & GF_SEED_FILTER_MASK)) {
@@ -611,7 +718,10 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             if (ty == GF_TYPE_UNIQUE) K = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
             else if (ty != GF_TYPE_DUPES) {  // absent or >= 6 sites: no vote
               kill[s >> 1] |= 1u << (16 * (s & 1));
-              if (ty == GF_TYPE_HIGH) khigh[s >> 1] |= 1u << (16 * (s & 1));
+              if (ty == GF_TYPE_HIGH) {
+                khigh[s >> 1] |= 1u << (16 * (s & 1));
+                if (Krep == GF_NONE_LIN && (val & GF_LIN_MASK) != GF_LIN_MASK) Krep = (val & GF_LIN_MASK) - 32u * (uint32_t)s;
+              }
             }
           }
           // windows that cannot vote are not "clean" for what follows
@@ -654,9 +764,16 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             filt_done = true;
             if (nvalid < GF_MAJOR_KEYS / 2) {
               filt_dead = true;
+            } else if ((khigh[0] | khigh[1]) && Krep != GF_NONE_LIN) {
+              // a seed is in the table with six sites or more: most likely a read inside a repeat — verified against
+              // the copy of it that the key's representative site names, from the back of the queue (gf_high_queue_pass)
+              hqueued = true;
+#pragma unroll
+              for (int k = 0; k < NT; ++k) pp_q[k] = cwb[k];
+              K_q = Krep;
             } else if (khigh[0] | khigh[1]) {
-              // a seed is in the table with six sites or more: most likely a read inside a repeat, every window of
-              // which the filter will call present — it skips the rounds and goes on as it is; the bucket pass strikes
+              // ... and no representative to go by (the two-pass build keeps none): the filter will call its every
+              // window present — it skips the rounds and goes on as it is; the bucket pass strikes
               // its windows from one probe (gf_k_probe_buckets, r04).  Listing windows the filter was not asked about
               // as "filtered" is sound: the mark only says nobody need ask again.
 #pragma unroll
@@ -839,7 +956,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
           }
           // every other diagonal gets at most one vote per window that can still vote
           const int open = nvalid - v1;
-          if (queued) {
+          if (queued || hqueued) {
             // (decided by the queue's passes)
           } else if (v1 + open < GF_MAJOR_KEYS / 2 || open < GF_MINOR_KEYS / 2 || filt_dead) {
             counts[r] = 0;
@@ -862,15 +979,19 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (QUEUED) {
-        const uint64_t qm = __ballot(queued);
-        if (qm) {
-          const int n_new = __popcll(qm);
-          while (q_len + n_new > GF_FQ_CAP) q_len = gf_filter_queue_pass<PW>(T, s_q, q_len, lane, counts, my_list, &s_cnt);
-          if (queued) {  // the record = the read's list entry, its second word the round it is due
-            const int slot = q_len + gf_lanes_below(qm);
+        const uint64_t qm = __ballot(queued), hm = __ballot(hqueued);
+        if (qm | hm) {
+          const int n_new = __popcll(qm), n_newh = __popcll(hm);
+          while (q_len + q_back + n_new + n_newh > GF_FQ_CAP) {  // (rare: room is made at the fuller end)
+            if (q_len >= q_back) q_len = gf_filter_queue_pass<PW>(T, s_q, q_len, lane, counts, my_list, &s_cnt);
+            else q_back = gf_high_queue_pass<PW>(T, s_q, q_back, lane, counts, my_list, &s_cnt);
+          }
+          if (queued || hqueued) {
+            // the record = the read's list entry; its second word the round it is due (front) or its diagonal (back)
+            const int slot = queued ? q_len + gf_lanes_below(qm) : GF_FQ_CAP - 1 - q_back - gf_lanes_below(hm);
             uint32_t ew[16];
             ew[0] = (uint32_t)r;
-            ew[1] = 0u;
+            ew[1] = queued ? 0u : K_q;
 #pragma unroll
             for (int k = 0; k < NT; ++k) ew[2 + k] = pp_q[k];
 #pragma unroll
@@ -883,6 +1004,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             }
           }
           q_len += n_new;
+          q_back += n_newh;
           gf_wave_lds_sync();
         }
       }
@@ -939,6 +1061,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
       }
       if constexpr (QUEUED) {
         while (q_len >= 64) q_len = gf_filter_queue_pass<PW>(T, s_q, q_len, lane, counts, my_list, &s_cnt);
+        while (q_back >= 64) q_back = gf_high_queue_pass<PW>(T, s_q, q_back, lane, counts, my_list, &s_cnt);
       }
       if (batch_max > lmax) {  // (wave-uniform) batches with longer reads only
         const unsigned int s1 = gf_wave_append(long1k, ctr + 2);
@@ -951,6 +1074,7 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
   }
   if constexpr (QUEUED) {  // what is left of the wave's queue
     while (q_len > 0) q_len = gf_filter_queue_pass<PW>(T, s_q, q_len, lane, counts, my_list, &s_cnt);
+    while (q_back > 0) q_back = gf_high_queue_pass<PW>(T, s_q, q_back, lane, counts, my_list, &s_cnt);
   }
   __syncthreads();
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt;
