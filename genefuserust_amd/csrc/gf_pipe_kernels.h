@@ -965,6 +965,14 @@ __global__ __launch_bounds__(256, PW <= 10 ? GF_SVS_WAVES_PER_SIMD : 4) void gf_
             e_v1v2 = GF_ENTRY_FILTERED;  // v1 = v2 = 0; the windows below have been through the filter
 #pragma unroll
             for (int k = 0; k < NT; ++k) e_todo[k] = pp[k];
+          } else if (QUEUED && K != GF_NONE_LIN && (khigh[0] | khigh[1])) {
+            // undecided on its diagonal, and a seed of it is HIGH: a read across the edge of a repeat.  The windows
+            // inside the repeat equal HIGH-flagged sites on this same diagonal: the queue's back end strikes them
+            // (gf_high_queue_pass verifies on K once more, with both kinds of flags) and most such reads end there
+            hqueued = true;
+            K_q = K;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) pp_q[k] = cwb[k];
           } else {
             undecided = true;
             e_v1v2 = (uint32_t)v1;  // v2 = 0: one candidate diagonal per read

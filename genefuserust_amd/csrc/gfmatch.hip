@@ -479,10 +479,9 @@ static int launch_flat(const gf_index* idx, const GfTable& T, hipStream_t st, co
   const uint8_t* bases = src.bases;
   GF_HIP(hipMemsetAsync(w.ctr, 0, 64, st));
   if (ev) GF_HIP(hipEventRecord(ev[0], st));
-  // Seed+verify is bound by the line fills of its CU's L1, not by waves in flight: four blocks
-  // per CU (40 KB of LDS each, padded with dynamic LDS) measured 2.5 % faster than six.
-  // (r04: the PW = 10 kernel's queue of background reads takes 24 KB of LDS itself — 36 KB per block, four blocks per CU
-  //  again without padding; GF_SV_INLINE_ROUNDS builds, the r03 form, pad as before)
+  // Four blocks per CU: r03 padded the PW = 10 kernel's LDS to get there (2.5 % faster than six); since r04 its queue
+  // takes 24 KB itself — 40 KB per block, four per CU without padding (three cost 5.7 %, five or a smaller queue change
+  // nothing: the kernel is bound by instruction issue).  GF_SV_INLINE_ROUNDS builds, the r03 form, pad as before.
 #ifdef GF_SV_INLINE_ROUNDS
   size_t pad_lds = PW == 10 ? 24000 : 0;
 #else
