@@ -181,8 +181,10 @@ def test_rccl_exchange_through_the_c_abi_one_rank(gpu_device):
         assert torch.equal(merged[: t[0]].cpu(), hits[: int(n_hits)])
         merged, totals = ex.finish(h2)
         assert int(totals[0]) == 7 and torch.equal(merged[:7].cpu(), hits[:7])
+        assert ex.comm_world() == (0, 1)   # what RCCL reports from inside the communicator (bench.py: ranks_seen)
         small = RcclHitExchange(cap=100, device=dev)
-        _, totals = small.finish(small.start(hits.to(dev), n_hits.to(dev)))
+        # the first exchange as bench.py runs it: queued, agreed upon over the torch group, then waited for
+        _, totals = small.first_exchange(hits.to(dev), n_hits.to(dev))
         assert int(totals[1]) == 1 and int(totals[0]) == 100
         small.close()
         ex.close()
