@@ -199,10 +199,12 @@ def main() -> None:
         cfg["shape"] = args.shape
     if args.pairs:
         cfg["pairs"] = args.pairs
+    # defaults: about a second of timed region (46 ms inside a 22 s run is more than a driver's sampler of
+    # GPU activity can see), a few warm-up steps
     if args.steps is None:
-        args.steps = {1: 10, 2: 5, 3: 5, 4: 2}[args.config]
+        args.steps = {1: 500, 2: 30, 3: 50, 4: 6}[args.config]
     if args.warmup is None:
-        args.warmup = {1: 2, 2: 1, 3: 1, 4: 1}[args.config]
+        args.warmup = {1: 5, 2: 2, 3: 2, 4: 1}[args.config]
 
     import numpy as np
     import torch
