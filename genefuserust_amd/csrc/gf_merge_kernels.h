@@ -89,14 +89,15 @@ __device__ __forceinline__ uint32_t gf_len_mask2(int L, int j) {
 
 // like gf_convert16, but valid = ACGTacgt (the bytes whose reverse complement is not 'N')
 __device__ __forceinline__ void gf_convert16_nocase(const uint4& q, uint32_t& code32, uint32_t& bad16) {
-  const uint32_t y0 = (q.x >> 1) & 0x03030303u, y1 = (q.y >> 1) & 0x03030303u;
-  const uint32_t y2 = (q.z >> 1) & 0x03030303u, y3 = (q.w >> 1) & 0x03030303u;
-  const uint32_t d0 = (q.x & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, y0);
-  const uint32_t d1 = (q.y & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, y1);
-  const uint32_t d2 = (q.z & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, y2);
-  const uint32_t d3 = (q.w & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, y3);
-  code32 = ((y0 * 0x01041040u) >> 24) | (((y1 * 0x01041040u) >> 24) << 8) | (((y2 * 0x01041040u) >> 24) << 16) |
-           (((y3 * 0x01041040u) >> 24) << 24);
+  // (as gf_convert16: the doubled codes where they stand serve the table look-up and, by dot products, the packing)
+  const uint32_t z0 = q.x & 0x06060606u, z1 = q.y & 0x06060606u, z2 = q.z & 0x06060606u, z3 = q.w & 0x06060606u;
+  const uint32_t d0 = (q.x & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0x00470054u, 0x00430041u, z0);
+  const uint32_t d1 = (q.y & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0x00470054u, 0x00430041u, z1);
+  const uint32_t d2 = (q.z & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0x00470054u, 0x00430041u, z2);
+  const uint32_t d3 = (q.w & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0x00470054u, 0x00430041u, z3);
+  const uint32_t e0 = __builtin_amdgcn_udot4(z0, 0x40100401u, 0u, false), e1 = __builtin_amdgcn_udot4(z1, 0x40100401u, 0u, false);
+  const uint32_t e2 = __builtin_amdgcn_udot4(z2, 0x40100401u, 0u, false), e3 = __builtin_amdgcn_udot4(z3, 0x40100401u, 0u, false);
+  code32 = ((e0 + (e1 << 8) + (e2 << 16)) >> 1) | ((e3 >> 1) << 24);
   bad16 = 0;
   if (d0 | d1 | d2 | d3) {
     const uint32_t n0 = (((d0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d0) & 0x80808080u;

@@ -192,15 +192,18 @@ __device__ __forceinline__ uint32_t gf_clean16(uint32_t z_lo, uint32_t z_hi) {
 // 2-bit code comes from one v_perm_b32 table lookup; a chunk whose 16 bytes all equal their
 // expected letters (the usual case) is done without looking at single bytes.
 __device__ __forceinline__ void gf_convert16(const uint4& q, uint32_t& code32, uint32_t& bad16) {
-  const uint32_t y0 = (q.x >> 1) & 0x03030303u, y1 = (q.y >> 1) & 0x03030303u;
-  const uint32_t y2 = (q.z >> 1) & 0x03030303u, y3 = (q.w >> 1) & 0x03030303u;
-  // table bytes: code 0 'A', 1 'C', 2 'T', 3 'G'
-  const uint32_t d0 = q.x ^ __builtin_amdgcn_perm(0u, 0x47544341u, y0), d1 = q.y ^ __builtin_amdgcn_perm(0u, 0x47544341u, y1);
-  const uint32_t d2 = q.z ^ __builtin_amdgcn_perm(0u, 0x47544341u, y2), d3 = q.w ^ __builtin_amdgcn_perm(0u, 0x47544341u, y3);
-  // codes of 4 bases -> 8 bits: one dot product of the four bytes with (1, 4, 16, 64)
-  code32 = __builtin_amdgcn_udot4(y0, 0x40100401u, 0u, false) | (__builtin_amdgcn_udot4(y1, 0x40100401u, 0u, false) << 8) |
-           (__builtin_amdgcn_udot4(y2, 0x40100401u, 0u, false) << 16) |
-           (__builtin_amdgcn_udot4(y3, 0x40100401u, 0u, false) << 24);
+  // twice the code of each base, where it stands in its byte (bits 1, 2): one AND per dword serves both the table
+  // look-up of the expected letter and the packing (r04: the kernel is bound by instruction issue, and this runs for
+  // every 16 bases of every read — the shifts that made proper codes of them first were four instructions too many)
+  const uint32_t z0 = q.x & 0x06060606u, z1 = q.y & 0x06060606u, z2 = q.z & 0x06060606u, z3 = q.w & 0x06060606u;
+  // v_perm_b32 with selectors 0, 2, 4, 6: bytes 0 / 2 of the second operand are 'A' / 'C', bytes 0 / 2 of the first 'T' / 'G'
+  const uint32_t d0 = q.x ^ __builtin_amdgcn_perm(0x00470054u, 0x00430041u, z0), d1 = q.y ^ __builtin_amdgcn_perm(0x00470054u, 0x00430041u, z1);
+  const uint32_t d2 = q.z ^ __builtin_amdgcn_perm(0x00470054u, 0x00430041u, z2), d3 = q.w ^ __builtin_amdgcn_perm(0x00470054u, 0x00430041u, z3);
+  // codes of 4 bases -> 8 bits: one dot product of the four bytes with (1, 4, 16, 64) — of the doubled codes, so every
+  // sum is twice what it should be: three of them are added up where they belong and halved together
+  const uint32_t e0 = __builtin_amdgcn_udot4(z0, 0x40100401u, 0u, false), e1 = __builtin_amdgcn_udot4(z1, 0x40100401u, 0u, false);
+  const uint32_t e2 = __builtin_amdgcn_udot4(z2, 0x40100401u, 0u, false), e3 = __builtin_amdgcn_udot4(z3, 0x40100401u, 0u, false);
+  code32 = ((e0 + (e1 << 8) + (e2 << 16)) >> 1) | ((e3 >> 1) << 24);
   bad16 = 0;
   if (d0 | d1 | d2 | d3) {
     // bit 7 of each byte = that byte differs; gathered to one bit per base
