@@ -129,21 +129,6 @@ def traffic_entry(shape: str, n: int, L: int):
         return None
 
 
-class _TorchExchange:
-    """HitExchange (torch.distributed collectives) behind RcclHitExchange's start / finish shape: (merged, totals)."""
-
-    def __init__(self, ex):
-        self.ex, self.cap = ex, ex.cap
-
-    def start(self, hits, n_hits):
-        return self.ex.start(hits, n_hits)
-
-    def finish(self, handle):
-        import torch
-        merged, total, overflow = self.ex.finish(handle)
-        return merged, torch.cat([total.reshape(1), overflow.reshape(1).to(total.dtype)])
-
-
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` run plainly: start the N ranks as a CHILD torch.distributed.run (this process has not
     initialised the GPU and never will), let rank 0's JSON line through on our stdout, return the child's exit code."""
