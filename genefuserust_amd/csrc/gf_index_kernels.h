@@ -11,7 +11,9 @@
 // atomics), one pass over the gene bases (gf_k_index_insert: a key's first site is written with the
 // claim of its slot, later sites go to a side list), a sweep over the table (counters -> unique /
 // dupes(start in dupes[]) / HIGH, statistics), the side list into the duplicate lists (each sorted by the thread
-// that brings its last site).  The first form is kept behind GF_BUILD_TWO_PASS (experiments):
+// that brings its last site); the same pass over the side list flags every site of a HIGH key (the odd bit beside its
+// "unique" flag in gdu) and leaves the smallest of them in the key's slot (r04: what the mapping kernels prove "cannot
+// vote" from).  The first form is kept behind GF_BUILD_TWO_PASS (experiments; it keeps neither):
 //   COUNT   insert keys with 64-bit CAS, count occurrences
 //   classify (count -> unique / dupes(start in dupes[]) / HIGH)
 //   FILL    write site codes

@@ -529,7 +529,7 @@ static int launch_flat(const gf_index* idx, const GfTable& T, hipStream_t st, co
 extern "C" {
 
 const char* gf_last_error(void) { return g_err.c_str(); }
-const char* gf_version(void) { return "gfmatch 0.1.0 (gfx950)"; }
+const char* gf_version(void) { return "gfmatch 0.4.0 (gfx950)"; }
 
 int gf_index_build(const char* const* gene_seqs, const int64_t* gene_lens, int32_t n_genes,
                    const gf_options* opts, gf_index** out_index) {

@@ -122,7 +122,8 @@ int gf_index_trim(gf_index* idx);
 /* Test hook: one of the index's derived device arrays, copied to the host as it is.  Returns its size in
  * bytes (or a negative error) and copies min(cap, size) bytes to out when out != NULL.
  *   GF_EXPORT_GDU      uint32 pairs, one per 16 site codes: (both strands of the genes as 2-bit codes A0 C1 T2 G3,
- *                      the sites' "only site of its key" flags on the even bits)
+ *                      the sites' flags: even bit = "only site of its key", odd bit = "its key has six sites or more"
+ *                      — the keys that never vote, indexer.rs:202-239)
  *   GF_EXPORT_FILTER   the presence filter over canonical 14-mers, uint32 words
  *   GF_EXPORT_LIN_BASE uint32 per gene: the site code of its forward base 0 (forward base f = code + f,
  *                      reverse-strand base f = code - f)
