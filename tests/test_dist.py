@@ -258,3 +258,72 @@ def test_multi_csv_groups_of_four_ranks_gloo():
         assert (np.diff(merged[:, 0]) > 0).all()
         # the second batch: every rank of the group sent its first min(3, count) records
         assert t2 == sum(min(3, int(_csv_hits(csv, *shard_range(n, p, 4), cap=n)[1])) for p in range(4))
+
+
+def _rccl_worker(rank, world, port, q):
+    """One rank of the two-GPU RCCL test: its own device, torch's nccl group for the id and the agreements, the exchange
+    through the C ABI."""
+    from genefuserust_amd.dist import RcclHitExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        n = 9001
+        lo, hi = shard_range(n, rank, world)
+        hits, n_hits = _fake_hits(lo, hi, cap=hi - lo + 1)   # ragged: the shards' counts differ
+        ex = RcclHitExchange(cap=2048, device=dev)
+        assert ex.comm_world() == (rank, world)
+        merged, totals = ex.first_exchange(hits.to(dev), n_hits.to(dev))
+        t = totals.cpu().tolist()
+        q.put((rank, "first", merged[: t[0]].cpu().numpy().copy(), t))
+        # two batches in flight: the whole list, then only this rank's first five records
+        ha = ex.start(hits.to(dev), n_hits.to(dev))
+        hb = ex.start(hits[:5].to(dev), torch.tensor([5], device=dev))
+        for tag, h in (("a", ha), ("b", hb)):
+            merged, totals = ex.finish(h)
+            torch.cuda.synchronize(dev)
+            t = totals.cpu().tolist()
+            q.put((rank, tag, merged[: t[0]].cpu().numpy().copy(), t))
+        small = RcclHitExchange(cap=16, device=dev)           # over capacity on every rank: reported, not cut silently
+        _, totals = small.first_exchange(hits.to(dev), n_hits.to(dev))
+        q.put((rank, "small", None, totals.cpu().tolist()))
+        small.close()
+        ex.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_two_ranks_on_two_gpus():
+    """gf_allgather_hits_device between two ranks over RCCL — ragged counts, two batches in flight, overflow — on a box
+    with at least two GPUs.  The pool's boxes have one: there this test is skipped, and the first run of
+    the exchange over xGMI is the driver's scaling run."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    world, n = 2, 9001
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(4 * world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want, cnt = _fake_hits(0, n, cap=n)
+    want = want[: int(cnt)].numpy()
+    per_rank = [int(_fake_hits(*shard_range(n, r, world), cap=n)[1]) for r in range(world)]
+    for rank, tag, merged, t in got:
+        if tag in ("first", "a"):
+            assert t[0] == int(cnt) and t[1] == 0 and t[2:2 + world] == per_rank
+            assert np.array_equal(merged, want)
+        elif tag == "b":
+            assert t[0] == 5 * world and t[1] == 0
+            firsts = np.concatenate([_fake_hits(*shard_range(n, r, world), cap=n)[0][:5].numpy() for r in range(world)])
+            assert np.array_equal(merged, firsts)
+        else:
+            assert t[1] == 1 and t[0] == 16 * world and t[2:2 + world] == per_rank
