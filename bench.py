@@ -289,10 +289,25 @@ def main() -> None:
             # A communicator that cannot be made, or cannot move data, fails the run on EVERY rank (RcclHitExchange agrees
             # over the torch group after each step that can fail on one rank alone): no switch to another path inside a
             # process that has touched the GPU.  GF_BENCH_PLAIN_ALLGATHER=1 is the explicit opt-out.
+            # ... and one that never comes back (a bootstrap that cannot reach its peers) ends the run with a message
+            # after GF_BENCH_RCCL_INIT_TIMEOUT_S seconds (default 300) instead of sitting there until the caller's clock.
+            import threading
+            init_done = threading.Event()
+            limit_s = float(os.environ.get("GF_BENCH_RCCL_INIT_TIMEOUT_S", "300"))
+
+            def _watch():
+                if not init_done.wait(limit_s):
+                    print("rank %d: the RCCL communicator / first exchange through the C ABI did not finish within %.0f s; "
+                          "rerun with GF_BENCH_PLAIN_ALLGATHER=1 to take torch.distributed's all-gather instead"
+                          % (rank, limit_s), file=sys.stderr, flush=True)
+                    os._exit(4)
+            threading.Thread(target=_watch, daemon=True).start()
             try:
                 exch = RcclHitExchange(cap=cap_x, device=dev)
                 exch.first_exchange(out_sets[0][0], nh)
+                init_done.set()
             except Exception as e:  # noqa: BLE001
+                init_done.set()
                 print("rank %d: RCCL exchange through the C ABI failed (%s: %s); rerun with GF_BENCH_PLAIN_ALLGATHER=1 to "
                       "take torch.distributed's all-gather instead" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
                 os._exit(3)   # (a peer's collective may still be waiting on the device: no destructors)
